@@ -1,0 +1,168 @@
+/*
+ * phantom_amd.h — C ABI of the MI355X-native RNS polynomial-arithmetic hot path.
+ *
+ * Drop-in boundary for Phantom-FHE's L4 seam: every entry point replaces the
+ * reference function cited next to it (paths relative to the reference tree).  Plain pointers
+ * and sizes only; no C++ / torch types.  All `uint64_t*` data arguments are DEVICE pointers
+ * (limb-major `[poly][limb][N]`, canonical residues in [0, q_i)) unless the name says `host`.
+ * All compute entry points are asynchronous on `stream` (a `hipStream_t` passed as void*;
+ * NULL = the HIP default stream), return 0 on success or a negative PHA_ERR_* code, and never
+ * synchronise the host.  Argument errors that make the reference throw std::invalid_argument /
+ * std::logic_error return PHA_ERR_INVALID_ARGUMENT / PHA_ERR_LOGIC here; pha_last_error() has
+ * the message.  HIP API failures return PHA_ERR_HIP (the reference calls std::exit there).
+ *
+ * Not thread-safe per context (like the reference: one stream, one context); scratch buffers
+ * are owned by the context and sized for the largest level on first use.
+ */
+#ifndef PHANTOM_AMD_H
+#define PHANTOM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHA_OK 0
+#define PHA_ERR_INVALID_ARGUMENT (-1)
+#define PHA_ERR_LOGIC (-2)
+#define PHA_ERR_HIP (-3)
+#define PHA_ERR_NO_DEVICE (-4)
+
+typedef struct pha_context pha_context;
+typedef void *pha_stream_t; /* hipStream_t */
+
+/* ---- library ------------------------------------------------------------------------- */
+const char *pha_last_error(void);
+const char *pha_version(void);
+
+/* ---- host number theory (no GPU needed) ------------------------------------------------ */
+/* CoeffModulus::Create (src/modulus.cu:79-110, src/util/numth.cu:209-235) */
+int pha_coeff_modulus_create(size_t poly_modulus_degree, const int *bit_sizes, size_t count, uint64_t *out_moduli);
+/* arith::NTT::NTT table generation for one modulus (src/util/ntt.cu:11-56): host buffers of
+ * N words each; tw/itw are bit-reversed psi powers with N^-1 folded into itw[1]. */
+int pha_host_ntt_tables(int log_n, uint64_t modulus, uint64_t *tw, uint64_t *tw_shoup, uint64_t *itw,
+                        uint64_t *itw_shoup, uint64_t *n_inv, uint64_t *n_inv_shoup);
+/* Modulus::set_value Barrett ratio floor(2^128/q) as (lo, hi) (src/modulus.cu:28-40) */
+int pha_host_barrett_ratio(uint64_t modulus, uint64_t ratio[2]);
+/* PhantomGaloisTool permutation table (include/galois.cuh:49-64) and step -> element
+ * (src/galois.cu:42-75); host buffers */
+int pha_host_galois_table(int log_n, uint32_t galois_elt, uint32_t *table);
+int pha_galois_elt_from_step(int log_n, int step, uint32_t *out_elt);
+/* DRNSTool level constants (src/rns.cu:60-192) for the data level with size_Ql limbs of the
+ * chain `moduli_QP` (last size_P are the special primes); host buffers, any may be NULL:
+ * inv_q_last_mod_q[size_Ql-1], bigP_mod_q[size_Ql], bigPInv_mod_q[size_Ql],
+ * partQlHatInv_mod_Ql_concat[size_Ql]. */
+int pha_host_level_constants(const uint64_t *moduli_QP, size_t size_QP, size_t size_P, size_t size_Ql,
+                             uint64_t *inv_q_last_mod_q, uint64_t *bigP_mod_q, uint64_t *bigPInv_mod_q,
+                             uint64_t *partQlHatInv_mod_Ql_concat);
+
+/* ---- context: PhantomContext + DNTTTable + per-level DRNSTool (src/context.cu:120-290) --- */
+/* moduli_QP = key-level coeff_modulus (Q then P); size_P = special_modulus_size
+ * (include/util/encryptionparams.h:375, default 1).  Uses the current HIP device. */
+int pha_context_create(int log_n, const uint64_t *moduli_QP, size_t size_QP, size_t size_P, pha_context **out);
+void pha_context_destroy(pha_context *ctx);
+size_t pha_context_n(const pha_context *ctx);
+size_t pha_context_size_QP(const pha_context *ctx);
+size_t pha_context_size_P(const pha_context *ctx);
+/* copy the key-level moduli / the canonical (reference-layout) tables of one limb to host:
+ * which = 0 twiddle, 1 twiddle_shoup, 2 itwiddle, 3 itwiddle_shoup (N words)  (include/gputype.h:51-146) */
+int pha_context_get_moduli(const pha_context *ctx, uint64_t *out_host);
+int pha_context_get_table(const pha_context *ctx, size_t limb, int which, uint64_t *out_host);
+
+/* ---- NTT family (include/ntt.cuh:47-94).  Buffers are [limb][N]; limb indices absolute. --- */
+/* nwt_2d_radix8_forward_inplace (src/ntt/fntt_2d.cu:620-653) */
+int pha_nwt_2d_radix8_forward_inplace(pha_context *ctx, uint64_t *inout, size_t coeff_modulus_size,
+                                      size_t start_modulus_idx, pha_stream_t stream);
+/* nwt_2d_radix8_backward_inplace (src/ntt/intt_2d.cu:724-757) */
+int pha_nwt_2d_radix8_backward_inplace(pha_context *ctx, uint64_t *inout, size_t coeff_modulus_size,
+                                       size_t start_modulus_idx, pha_stream_t stream);
+/* nwt_2d_radix8_backward, out-of-place (src/ntt/ntt_modup.cu:320-354) */
+int pha_nwt_2d_radix8_backward(pha_context *ctx, uint64_t *out, const uint64_t *in, size_t coeff_modulus_size,
+                               size_t start_modulus_idx, pha_stream_t stream);
+/* nwt_2d_radix8_backward_scale: INTT then x scale[limb] (src/ntt/ntt_modup.cu:356-393);
+ * scale / scale_shoup are device arrays indexed by absolute limb */
+int pha_nwt_2d_radix8_backward_scale(pha_context *ctx, uint64_t *out, const uint64_t *in, size_t coeff_modulus_size,
+                                     size_t start_modulus_idx, const uint64_t *scale, const uint64_t *scale_shoup,
+                                     pha_stream_t stream);
+/* nwt_2d_radix8_forward_inplace_include_special_mod (src/ntt/fntt_2d.cu:695-736) */
+int pha_nwt_2d_radix8_forward_inplace_include_special_mod(pha_context *ctx, uint64_t *inout,
+                                                          size_t coeff_modulus_size, size_t start_modulus_idx,
+                                                          size_t size_QP, size_t size_P, pha_stream_t stream);
+/* nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range (src/ntt/ntt_modup.cu:610-657) */
+int pha_nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range(
+    pha_context *ctx, uint64_t *inout, size_t coeff_modulus_size, size_t start_modulus_idx, size_t size_QP,
+    size_t size_P, size_t excluded_range_start, size_t excluded_range_end, pha_stream_t stream);
+/* nwt_2d_radix8_backward_inplace_include_special_mod (src/ntt/intt_2d.cu:796-834) */
+int pha_nwt_2d_radix8_backward_inplace_include_special_mod(pha_context *ctx, uint64_t *inout,
+                                                           size_t coeff_modulus_size, size_t start_modulus_idx,
+                                                           size_t size_QP, size_t size_P, pha_stream_t stream);
+/* nwt_2d_radix8_forward_inplace_fuse_moddown (src/ntt/ntt_moddown.cu:222-261):
+ * delta <- NTT(delta) (delta is scratch afterwards); ct = (cx - NTT(delta)) * bigPInv mod q */
+int pha_nwt_2d_radix8_forward_inplace_fuse_moddown(pha_context *ctx, uint64_t *ct, const uint64_t *cx,
+                                                   const uint64_t *bigPInv_mod_q,
+                                                   const uint64_t *bigPInv_mod_q_shoup, uint64_t *delta,
+                                                   size_t coeff_modulus_size, size_t start_modulus_idx,
+                                                   pha_stream_t stream);
+/* Extension (no reference counterpart): the same forward / inverse transform over `polys`
+ * buffers `[polys][limb_stride_limbs][N]` in one launch pair, sharing each limb's twiddles
+ * across the polys (config 2 of BASELINE.json: 2 polys x 36 limbs). */
+int pha_ntt_forward_batched(pha_context *ctx, uint64_t *inout, size_t polys, size_t poly_stride_limbs,
+                            size_t coeff_modulus_size, size_t start_modulus_idx, pha_stream_t stream);
+int pha_ntt_backward_batched(pha_context *ctx, uint64_t *inout, size_t polys, size_t poly_stride_limbs,
+                             size_t coeff_modulus_size, size_t start_modulus_idx, pha_stream_t stream);
+
+/* ---- DRNSTool (include/rns.cuh:155-185); chain_index as in the reference:
+ *      1 = first data level (all of Q), k = Q minus its last k-1 primes (src/context.cu:148-174) */
+/* DRNSTool::modup, CKKS branch (src/rns_bconv.cu:530-628): dst[beta][size_QlP][N] */
+int pha_modup(pha_context *ctx, size_t chain_index, uint64_t *dst, const uint64_t *cks, pha_stream_t stream);
+/* key_switch_inner_prod (src/eval_key_switch.cu:12-88): evks = device array of beta device
+ * pointers, each a key-level `[2][size_QP][N]` buffer (PhantomRelinKey::public_keys_ptr,
+ * include/secretkey.h:85-113).  reduction_threshold is accepted for signature parity and
+ * ignored: the result is the canonical residue either way. */
+int pha_key_switch_inner_prod(pha_context *ctx, size_t chain_index, uint64_t *p_cx, const uint64_t *p_t_mod_up,
+                              const uint64_t *const *evks, size_t reduction_threshold, pha_stream_t stream);
+/* DRNSTool::moddown_from_NTT, CKKS branch (src/rns_bconv.cu:776-828); destroys cx_i's P limbs */
+int pha_moddown_from_ntt(pha_context *ctx, size_t chain_index, uint64_t *ct_i, uint64_t *cx_i, pha_stream_t stream);
+/* add_to_ct_kernel (src/rns_bconv.cu:763-769): ct[limbs][N] += cx[limbs][N] */
+int pha_add_to_ct(pha_context *ctx, uint64_t *ct, const uint64_t *cx, size_t size_Ql, pha_stream_t stream);
+/* keyswitch_inplace, CKKS branch (src/eval_key_switch.cu:91-178): ct[2][size_Ql][N] += KS(c2) */
+int pha_keyswitch_inplace(pha_context *ctx, size_t chain_index, uint64_t *ct, const uint64_t *c2,
+                          const uint64_t *const *evks, pha_stream_t stream);
+/* DRNSTool::divide_and_round_q_last_ntt (src/rns.cu:1157-1181); destroys src's last limb */
+int pha_divide_and_round_q_last_ntt(pha_context *ctx, size_t chain_index, uint64_t *src, size_t cipher_size,
+                                    uint64_t *dst, pha_stream_t stream);
+
+/* ---- Galois (include/galois.cuh:134-135, src/galois.cu:8-18,122-138) ---------------------- */
+/* result[l][i] = operand[l][perm_g[i]]; result may equal operand (a context scratch buffer is
+ * used then, like the reference's temporary).  The table for galois_elt is built and cached
+ * on first use. */
+int pha_apply_galois_ntt(pha_context *ctx, const uint64_t *operand, size_t coeff_mod_size, uint32_t galois_elt,
+                         uint64_t *result, pha_stream_t stream);
+
+/* ---- tensor products (src/polymath.cu:468-537) ------------------------------------------- */
+/* result[3][limbs][N] from operand1[2][limbs][N], operand2[2][limbs][N]; result may alias
+ * neither operand */
+int pha_tensor_prod_2x2(pha_context *ctx, const uint64_t *operand1, const uint64_t *operand2, size_t coeff_mod_size,
+                        uint64_t *result, pha_stream_t stream);
+int pha_tensor_square_2x2(pha_context *ctx, const uint64_t *operand, size_t coeff_mod_size, uint64_t *result,
+                          pha_stream_t stream);
+
+/* ---- evaluator composites the host keeps (include/evaluate.cuh:114-294) ------------------ */
+/* multiply_internal + relinearize_inplace (src/evaluate.cu:229-280,553-583): ct1[2][l][N] *= ct2,
+ * then relinearised with evks; ct1 must have room for 3 polys (the reference resizes) */
+int pha_multiply_and_relin_inplace(pha_context *ctx, size_t chain_index, uint64_t *ct1, const uint64_t *ct2,
+                                   const uint64_t *const *relin_evks, pha_stream_t stream);
+/* apply_galois_inplace (src/evaluate.cu:747-794): ct[2][l][N] rotated by galois_elt */
+int pha_apply_galois_inplace(pha_context *ctx, size_t chain_index, uint64_t *ct, uint32_t galois_elt,
+                             const uint64_t *const *galois_evks, pha_stream_t stream);
+/* rescale_to_next / mod_switch_scale_to_next (src/evaluate.cu:585-616,725-745):
+ * dst[2][l-1][N] from src[2][l][N]; src is preserved (the reference copies first) */
+int pha_rescale_to_next(pha_context *ctx, size_t chain_index, const uint64_t *src, size_t cipher_size,
+                        uint64_t *dst, pha_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHANTOM_AMD_H */

@@ -1,0 +1,316 @@
+"""phantom-fhe_amd — MI355X-native RNS polynomial arithmetic (Phantom-FHE hot path).
+
+This package is a thin ctypes binding over the C ABI declared in ``include/phantom_amd.h``
+(built in-tree as ``phantom-fhe_amd/libphantom_amd.so`` by ``__graft_entry__.build()``).
+There is no CPU fallback: importing works without a GPU (so the symbol / host-logic tests can
+run), but every compute entry point needs the HIP library and a device and fails loudly
+otherwise.  PyTorch is used only for device memory and streams.
+
+The directory name contains a hyphen (it is the name the project layout prescribes); import it
+as ``phantom_fhe_amd`` through the shim module at the repository root.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libphantom_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "phantom_amd.h")
+
+PHA_OK = 0
+PHA_ERR_INVALID_ARGUMENT = -1
+PHA_ERR_LOGIC = -2
+PHA_ERR_HIP = -3
+PHA_ERR_NO_DEVICE = -4
+
+_u64 = ctypes.c_uint64
+_u32 = ctypes.c_uint32
+_sz = ctypes.c_size_t
+_int = ctypes.c_int
+_vp = ctypes.c_void_p
+_u64p = ctypes.POINTER(_u64)
+_u32p = ctypes.POINTER(_u32)
+_intp = ctypes.POINTER(_int)
+
+# name -> (restype, argtypes); must cover every function declared in include/phantom_amd.h
+SIGNATURES = {
+    "pha_last_error": (ctypes.c_char_p, []),
+    "pha_version": (ctypes.c_char_p, []),
+    "pha_coeff_modulus_create": (_int, [_sz, _intp, _sz, _u64p]),
+    "pha_host_ntt_tables": (_int, [_int, _u64, _u64p, _u64p, _u64p, _u64p, _u64p, _u64p]),
+    "pha_host_barrett_ratio": (_int, [_u64, _u64p]),
+    "pha_host_galois_table": (_int, [_int, _u32, _u32p]),
+    "pha_galois_elt_from_step": (_int, [_int, _int, _u32p]),
+    "pha_host_level_constants": (_int, [_u64p, _sz, _sz, _sz, _u64p, _u64p, _u64p, _u64p]),
+    "pha_context_create": (_int, [_int, _u64p, _sz, _sz, ctypes.POINTER(_vp)]),
+    "pha_context_destroy": (None, [_vp]),
+    "pha_context_n": (_sz, [_vp]),
+    "pha_context_size_QP": (_sz, [_vp]),
+    "pha_context_size_P": (_sz, [_vp]),
+    "pha_context_get_moduli": (_int, [_vp, _u64p]),
+    "pha_context_get_table": (_int, [_vp, _sz, _int, _u64p]),
+    "pha_nwt_2d_radix8_forward_inplace": (_int, [_vp, _vp, _sz, _sz, _vp]),
+    "pha_nwt_2d_radix8_backward_inplace": (_int, [_vp, _vp, _sz, _sz, _vp]),
+    "pha_nwt_2d_radix8_backward": (_int, [_vp, _vp, _vp, _sz, _sz, _vp]),
+    "pha_nwt_2d_radix8_backward_scale": (_int, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    "pha_nwt_2d_radix8_forward_inplace_include_special_mod": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "pha_nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range": (
+        _int, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _vp]),
+    "pha_nwt_2d_radix8_backward_inplace_include_special_mod": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "pha_nwt_2d_radix8_forward_inplace_fuse_moddown": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp]),
+    "pha_ntt_forward_batched": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "pha_ntt_backward_batched": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "pha_modup": (_int, [_vp, _sz, _vp, _vp, _vp]),
+    "pha_key_switch_inner_prod": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _vp]),
+    "pha_moddown_from_ntt": (_int, [_vp, _sz, _vp, _vp, _vp]),
+    "pha_add_to_ct": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "pha_keyswitch_inplace": (_int, [_vp, _sz, _vp, _vp, _vp, _vp]),
+    "pha_divide_and_round_q_last_ntt": (_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "pha_apply_galois_ntt": (_int, [_vp, _vp, _sz, _u32, _vp, _vp]),
+    "pha_tensor_prod_2x2": (_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "pha_tensor_square_2x2": (_int, [_vp, _vp, _sz, _vp, _vp]),
+    "pha_multiply_and_relin_inplace": (_int, [_vp, _sz, _vp, _vp, _vp, _vp]),
+    "pha_apply_galois_inplace": (_int, [_vp, _sz, _vp, _u32, _vp, _vp]),
+    "pha_rescale_to_next": (_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
+}
+
+_lib = None
+
+
+class PhantomError(RuntimeError):
+    """C ABI call failed (std::invalid_argument / std::logic_error / HIP failure in the reference)."""
+
+    def __init__(self, code, message):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+
+
+def lib():
+    """Load libphantom_amd.so (once).  Raises ImportError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def _check(rc):
+    if rc != PHA_OK:
+        raise PhantomError(rc, lib().pha_last_error().decode())
+
+
+def _np_u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(_u64p)
+
+
+# ---- host number theory (no GPU) ---------------------------------------------------------------
+def coeff_modulus_create(poly_modulus_degree, bit_sizes):
+    """CoeffModulus::Create (src/modulus.cu:79-110)."""
+    bits = (_int * len(bit_sizes))(*bit_sizes)
+    out = np.zeros(len(bit_sizes), dtype=np.uint64)
+    _check(lib().pha_coeff_modulus_create(poly_modulus_degree, bits, len(bit_sizes), out.ctypes.data_as(_u64p)))
+    return out
+
+
+def host_ntt_tables(log_n, modulus):
+    n = 1 << log_n
+    arrs = [np.zeros(n, dtype=np.uint64) for _ in range(4)]
+    ni, nis = _u64(), _u64()
+    _check(lib().pha_host_ntt_tables(log_n, int(modulus), *[a.ctypes.data_as(_u64p) for a in arrs],
+                                     ctypes.byref(ni), ctypes.byref(nis)))
+    return (*arrs, ni.value, nis.value)
+
+
+def host_barrett_ratio(modulus):
+    r = (_u64 * 2)()
+    _check(lib().pha_host_barrett_ratio(int(modulus), r))
+    return int(r[0]), int(r[1])
+
+
+def host_galois_table(log_n, elt):
+    t = np.zeros(1 << log_n, dtype=np.uint32)
+    _check(lib().pha_host_galois_table(log_n, int(elt), t.ctypes.data_as(_u32p)))
+    return t
+
+
+def galois_elt_from_step(log_n, step):
+    e = _u32()
+    _check(lib().pha_galois_elt_from_step(log_n, int(step), ctypes.byref(e)))
+    return e.value
+
+
+def host_level_constants(moduli_qp, size_p, size_ql):
+    m, mp = _np_u64(moduli_qp)
+    outs = [np.zeros(max(size_ql - 1, 0), dtype=np.uint64)] + [np.zeros(size_ql, dtype=np.uint64) for _ in range(3)]
+    _check(lib().pha_host_level_constants(mp, len(m), size_p, size_ql, *[o.ctypes.data_as(_u64p) for o in outs]))
+    return dict(inv_q_last_mod_q=outs[0], bigP_mod_q=outs[1], bigPInv_mod_q=outs[2],
+                partQlHatInv_mod_Ql_concat=outs[3])
+
+
+# ---- device side ------------------------------------------------------------------------------
+def _ptr(t):
+    """Device pointer of a torch tensor (int64 storage of uint64 words) or raw int."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    assert t.is_cuda and t.is_contiguous(), "device tensors must be contiguous CUDA(HIP) tensors"
+    return t.data_ptr()
+
+
+def to_device(a, device="cuda"):
+    """numpy uint64 array -> torch int64 device tensor with the same bit pattern."""
+    import torch
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return torch.from_numpy(a.view(np.int64)).to(device)
+
+
+def to_host(t):
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+def _stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+class EvalKey:
+    """PhantomRelinKey layout (include/secretkey.h:85-113): beta device buffers [2][size_QP][N] plus
+    a device array of their pointers."""
+
+    def __init__(self, digits):
+        import torch
+        self.digits = list(digits)
+        ptrs = np.array([d.data_ptr() for d in self.digits], dtype=np.uint64)
+        self.ptrs = torch.from_numpy(ptrs.view(np.int64)).to(self.digits[0].device)
+
+    @property
+    def ptr(self):
+        return self.ptrs.data_ptr()
+
+
+class PhantomContext:
+    """Mirror of PhantomContext + DNTTTable + DRNSTool (src/context.cu:120-290) over the C ABI."""
+
+    def __init__(self, log_n, moduli_qp, size_p=1):
+        self._h = _vp()
+        self.log_n = log_n
+        self.n = 1 << log_n
+        self.moduli = np.ascontiguousarray(moduli_qp, dtype=np.uint64)
+        self.size_QP = len(self.moduli)
+        self.size_P = size_p
+        self.size_Q = self.size_QP - size_p
+        _check(lib().pha_context_create(log_n, self.moduli.ctypes.data_as(_u64p), self.size_QP, size_p,
+                                        ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().pha_context_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size_Ql(self, chain_index):
+        return self.size_Q - (chain_index - 1)
+
+    def beta(self, chain_index):
+        return -(-self.size_Ql(chain_index) // self.size_P)
+
+    def get_table(self, limb, which):
+        out = np.zeros(self.n, dtype=np.uint64)
+        _check(lib().pha_context_get_table(self._h, limb, which, out.ctypes.data_as(_u64p)))
+        return out
+
+    # NTT family -------------------------------------------------------------------------------
+    def nwt_2d_radix8_forward_inplace(self, inout, count, start=0):
+        _check(lib().pha_nwt_2d_radix8_forward_inplace(self._h, _ptr(inout), count, start, _stream()))
+
+    def nwt_2d_radix8_backward_inplace(self, inout, count, start=0):
+        _check(lib().pha_nwt_2d_radix8_backward_inplace(self._h, _ptr(inout), count, start, _stream()))
+
+    def nwt_2d_radix8_backward(self, out, inp, count, start=0):
+        _check(lib().pha_nwt_2d_radix8_backward(self._h, _ptr(out), _ptr(inp), count, start, _stream()))
+
+    def nwt_2d_radix8_backward_scale(self, out, inp, count, start, scale, scale_shoup):
+        _check(lib().pha_nwt_2d_radix8_backward_scale(self._h, _ptr(out), _ptr(inp), count, start, _ptr(scale),
+                                                      _ptr(scale_shoup), _stream()))
+
+    def nwt_2d_radix8_forward_inplace_include_special_mod(self, inout, count, start, size_qp, size_p):
+        _check(lib().pha_nwt_2d_radix8_forward_inplace_include_special_mod(self._h, _ptr(inout), count, start,
+                                                                           size_qp, size_p, _stream()))
+
+    def nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range(self, inout, count, start, size_qp, size_p,
+                                                                        excl_start, excl_end):
+        _check(lib().pha_nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range(
+            self._h, _ptr(inout), count, start, size_qp, size_p, excl_start, excl_end, _stream()))
+
+    def nwt_2d_radix8_backward_inplace_include_special_mod(self, inout, count, start, size_qp, size_p):
+        _check(lib().pha_nwt_2d_radix8_backward_inplace_include_special_mod(self._h, _ptr(inout), count, start,
+                                                                            size_qp, size_p, _stream()))
+
+    def nwt_2d_radix8_forward_inplace_fuse_moddown(self, ct, cx, pinv, pinv_shoup, delta, count, start=0):
+        _check(lib().pha_nwt_2d_radix8_forward_inplace_fuse_moddown(self._h, _ptr(ct), _ptr(cx), _ptr(pinv),
+                                                                    _ptr(pinv_shoup), _ptr(delta), count, start,
+                                                                    _stream()))
+
+    def ntt_forward_batched(self, inout, polys, poly_stride_limbs, count, start=0):
+        _check(lib().pha_ntt_forward_batched(self._h, _ptr(inout), polys, poly_stride_limbs, count, start, _stream()))
+
+    def ntt_backward_batched(self, inout, polys, poly_stride_limbs, count, start=0):
+        _check(lib().pha_ntt_backward_batched(self._h, _ptr(inout), polys, poly_stride_limbs, count, start, _stream()))
+
+    # DRNSTool ---------------------------------------------------------------------------------
+    def modup(self, chain_index, dst, cks):
+        _check(lib().pha_modup(self._h, chain_index, _ptr(dst), _ptr(cks), _stream()))
+
+    def key_switch_inner_prod(self, chain_index, cx, t_mod_up, evk, reduction_threshold=0):
+        _check(lib().pha_key_switch_inner_prod(self._h, chain_index, _ptr(cx), _ptr(t_mod_up), evk.ptr,
+                                               reduction_threshold, _stream()))
+
+    def moddown_from_NTT(self, chain_index, ct_i, cx_i):
+        _check(lib().pha_moddown_from_ntt(self._h, chain_index, _ptr(ct_i), _ptr(cx_i), _stream()))
+
+    def add_to_ct(self, ct, cx, size_ql):
+        _check(lib().pha_add_to_ct(self._h, _ptr(ct), _ptr(cx), size_ql, _stream()))
+
+    def keyswitch_inplace(self, chain_index, ct, c2, evk):
+        _check(lib().pha_keyswitch_inplace(self._h, chain_index, _ptr(ct), _ptr(c2), evk.ptr, _stream()))
+
+    def divide_and_round_q_last_ntt(self, chain_index, src, cipher_size, dst):
+        _check(lib().pha_divide_and_round_q_last_ntt(self._h, chain_index, _ptr(src), cipher_size, _ptr(dst),
+                                                     _stream()))
+
+    # Galois / tensor --------------------------------------------------------------------------
+    def apply_galois_ntt(self, operand, coeff_mod_size, galois_elt, result):
+        _check(lib().pha_apply_galois_ntt(self._h, _ptr(operand), coeff_mod_size, galois_elt, _ptr(result), _stream()))
+
+    def tensor_prod_2x2(self, op1, op2, coeff_mod_size, result):
+        _check(lib().pha_tensor_prod_2x2(self._h, _ptr(op1), _ptr(op2), coeff_mod_size, _ptr(result), _stream()))
+
+    def tensor_square_2x2(self, op, coeff_mod_size, result):
+        _check(lib().pha_tensor_square_2x2(self._h, _ptr(op), coeff_mod_size, _ptr(result), _stream()))
+
+    # evaluator composites (include/evaluate.cuh) ---------------------------------------------
+    def multiply_and_relin_inplace(self, chain_index, ct1, ct2, relin_key):
+        _check(lib().pha_multiply_and_relin_inplace(self._h, chain_index, _ptr(ct1), _ptr(ct2), relin_key.ptr,
+                                                    _stream()))
+
+    def apply_galois_inplace(self, chain_index, ct, galois_elt, galois_key):
+        _check(lib().pha_apply_galois_inplace(self._h, chain_index, _ptr(ct), galois_elt, galois_key.ptr, _stream()))
+
+    def rescale_to_next(self, chain_index, src, cipher_size, dst):
+        _check(lib().pha_rescale_to_next(self._h, chain_index, _ptr(src), cipher_size, _ptr(dst), _stream()))

@@ -1,0 +1,340 @@
+// Negacyclic NTT / INTT kernels for gfx950 (the nwt_2d_radix8_* family of the reference,
+// include/ntt.cuh:47-94, re-designed for CDNA4).
+//
+// Decomposition (N = 2^logN, S1 + S2 = logN, both <= 8):
+//   column kernel: the S1 strided stages (t >= n2) on a [2^S1 rows][C cols] tile, two register
+//                  radix-2^RA / 2^RB passes with one LDS exchange; all tiles of a limb share the
+//                  same 2^S1 twiddles
+//   row kernel:    the S2 contiguous stages on 4096 consecutive coefficients, two register
+//                  passes, one LDS exchange between them and one LDS transpose so that the HBM
+//                  side is read/written 16 B per lane, fully coalesced
+// A tile is 4096 coefficients (32 KiB) per 256-thread workgroup, 16 coefficients per lane.
+// Stage order and twiddle indices are exactly those of src/ntt/ntt_1d.cu:41-74,220-254
+// (tw[m + k], m = 1,2,..,N/2 forward; reversed for the inverse), so results are bit-identical
+// to the reference after the final reduction to [0,q).
+#pragma once
+
+#include "modarith.cuh"
+
+namespace pha {
+
+constexpr int kTile = 4096;
+constexpr int kThreads = 256;
+constexpr int kLdsWords = kTile + 512;
+
+struct LimbMap {
+    uint32_t start, count;          // buffer limbs [start, start+count)
+    uint32_t size_QP, size_P;       // size_P > 0: last size_P limbs of the range use key-level table
+                                    // indices size_QP - size_P + k (src/ntt/fntt_2d.cu:433-436)
+    uint32_t excl_start, excl_end;  // limbs skipped (src/ntt/ntt_modup.cu:422); empty if start >= end
+};
+
+struct NttTables {
+    const DModulus *mod;   // [size_QP]
+    const tw_t *tw;        // [size_QP][n] canonical order {w, w_shoup}
+    const tw_t *twD;       // [size_QP][(n >> RB) / 64][2^RB - 1][64] last-pass order
+    const uint64_t *n_inv, *n_inv_shoup;  // [size_QP]
+    uint32_t log_n;
+    uint32_t twD_stride;   // records per limb in twD
+};
+
+// out[l][e] = (sub[l][e] - x) * cst[l] (+ addend[l][e])   or   x * cst[l]
+struct Epilogue {
+    uint64_t *out;
+    const uint64_t *sub;
+    const uint64_t *addend;
+    const uint64_t *cst, *cst_shoup;  // indexed by absolute buffer limb
+    size_t out_poly_stride, sub_poly_stride;
+};
+
+enum : int { EPI_NONE = 0, EPI_SUB_MUL = 1, EPI_SUB_MUL_ADD = 2, EPI_SCALE = 3 };
+
+__device__ __forceinline__ void resolve_limb(const LimbMap &m, uint32_t li, uint32_t &twr, uint32_t &tidx) {
+    twr = m.start + li;
+    if (m.excl_end > m.excl_start && twr >= m.excl_start) twr += m.excl_end - m.excl_start;
+    tidx = (m.size_P && twr >= m.start + m.count - m.size_P) ? m.size_QP - (m.start + m.count - twr) : twr;
+}
+
+struct CanonTw {
+    const tw_t *tw;
+    uint32_t node;
+    __device__ __forceinline__ tw_t operator()(int s, int jb) const { return tw[(node << s) + jb]; }
+};
+
+template <int RB>
+struct LastPassTw {
+    const tw_t *base;  // already offset to (chunk, lane)
+    __device__ __forceinline__ tw_t operator()(int s, int jb) const { return base[((1 << s) - 1 + jb) * 64]; }
+};
+
+// radix-2^R decimation-in-time block: stage s uses twiddle node*2^s + jb on sub-block jb
+template <int R, class Tw>
+__device__ __forceinline__ void ct_radix(uint64_t (&x)[1 << R], const Tw &tw, uint64_t q, uint64_t q2) {
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int half = 1 << (R - 1 - s);
+#pragma unroll
+        for (int jb = 0; jb < (1 << s); jb++) {
+            const tw_t w = tw(s, jb);
+#pragma unroll
+            for (int i = 0; i < half; i++) ct_butterfly(x[jb * 2 * half + i], x[jb * 2 * half + half + i], w, q, q2);
+        }
+    }
+}
+
+// inverse block; LAST: the final stage multiplies the sum half by N^-1 (the difference half gets
+// it through itw[1], src/util/ntt.cu:53-55) and reduces everything to [0,q)
+template <int R, bool LAST, class Tw>
+__device__ __forceinline__ void gs_radix(uint64_t (&x)[1 << R], const Tw &tw, uint64_t q, uint64_t q2, uint64_t n_inv = 0,
+                                         uint64_t n_inv_shoup = 0) {
+#pragma unroll
+    for (int s = R - 1; s >= (LAST ? 1 : 0); s--) {
+        const int half = 1 << (R - 1 - s);
+#pragma unroll
+        for (int jb = 0; jb < (1 << s); jb++) {
+            const tw_t w = tw(s, jb);
+#pragma unroll
+            for (int i = 0; i < half; i++) gs_butterfly(x[jb * 2 * half + i], x[jb * 2 * half + half + i], w, q, q2);
+        }
+    }
+    if (LAST) {
+        const int half = 1 << (R - 1);
+        const tw_t w = tw(0, 0);
+#pragma unroll
+        for (int i = 0; i < half; i++) {
+            const uint64_t a = x[i], b = x[half + i];
+            x[i] = csub(mul_shoup_lazy(a + b, n_inv, n_inv_shoup, q), q);
+            x[half + i] = csub(mul_shoup_lazy(a + q2 - b, w.x, w.y, q), q);
+        }
+    }
+}
+
+template <int C, int RB>
+__device__ __forceinline__ uint32_t lds_col(uint32_t r, uint32_t c) {
+    return r * C + c + (C == 16 ? (r >> RB) * 16 : 0);
+}
+__device__ __forceinline__ uint32_t lds_row(uint32_t e) { return e + ((e >> 4) << 1); }
+
+// ---------------------------------------------------------------------------------------------
+// forward, column phase: stages m = 1 .. 2^(S1-1)
+// ---------------------------------------------------------------------------------------------
+template <int S1, int RA>
+__global__ __launch_bounds__(kThreads) void fntt_col_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm) {
+    constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
+    __shared__ uint64_t lds[kLdsWords];
+    const uint32_t n = 1u << T.log_n, n2 = n >> S1, tiles = n >> 12;
+    const uint32_t li = blockIdx.x / tiles, ti = blockIdx.x % tiles;
+    uint32_t twr, tidx;
+    resolve_limb(lm, li, twr, tidx);
+    uint64_t *base = data + blockIdx.y * poly_stride + static_cast<size_t>(twr) * n + ti * C;
+    const uint64_t q = T.mod[tidx].value, q2 = q << 1;
+    const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
+    const uint32_t t = threadIdx.x;
+
+#pragma unroll
+    for (int g = 0; g < GA; g++) {
+        const uint32_t gid = t + kThreads * g, c = gid % C, r_lo = gid / C;
+        uint64_t x[1 << RA];
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) x[j] = base[static_cast<size_t>((j << RB) | r_lo) * n2 + c];
+        ct_radix<RA>(x, CanonTw{tw, 1u}, q, q2);
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) lds[lds_col<C, RB>((j << RB) | r_lo, c)] = x[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GB; g++) {
+        const uint32_t gid = t + kThreads * g, c = gid % C, r_hi = gid / C;
+        uint64_t x[1 << RB];
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) x[j] = lds[lds_col<C, RB>((r_hi << RB) | j, c)];
+        ct_radix<RB>(x, CanonTw{tw, (1u << RA) + r_hi}, q, q2);
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) base[static_cast<size_t>((r_hi << RB) | j) * n2 + c] = x[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward, row phase: stages m = 2^S1 .. N/2, final reduction to [0,q), optional fused epilogue
+// ---------------------------------------------------------------------------------------------
+template <int S2, int RA, int EPI>
+__global__ __launch_bounds__(kThreads) void fntt_row_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm,
+                                                            Epilogue ep) {
+    constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
+    __shared__ uint64_t lds[kLdsWords];
+    const uint32_t n = 1u << T.log_n, n1 = n >> S2, tiles = n >> 12;
+    const uint32_t li = blockIdx.x / tiles, ti = blockIdx.x % tiles;
+    uint32_t twr, tidx;
+    resolve_limb(lm, li, twr, tidx);
+    const size_t limb_off = static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
+    uint64_t *base = data + blockIdx.y * poly_stride + limb_off;
+    const DModulus mod = T.mod[tidx];
+    const uint64_t q = mod.value, q2 = q << 1;
+    const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
+    const uint32_t t = threadIdx.x;
+
+#pragma unroll
+    for (int g = 0; g < GC; g++) {
+        const uint32_t gid = t + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;
+        uint64_t x[1 << RA];
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) x[j] = base[a * L + ((j << RB) | b_lo)];
+        ct_radix<RA>(x, CanonTw{tw, n1 + ti * RW + a}, q, q2);
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) lds[lds_row(a * L + ((j << RB) | b_lo))] = x[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GD; g++) {
+        const uint32_t gid = t + kThreads * g, e0 = gid << RB;
+        const uint32_t ggid = ti * (kTile >> RB) + gid;
+        uint64_t x[1 << RB];
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) x[j] = lds[lds_row(e0 + j)];
+        const tw_t *twd = T.twD + static_cast<size_t>(tidx) * T.twD_stride +
+                          static_cast<size_t>(ggid >> 6) * (((1 << RB) - 1) * 64) + (ggid & 63);
+        ct_radix<RB>(x, LastPassTw<RB>{twd}, q, q2);
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) lds[lds_row(e0 + j)] = csub(csub(x[j], q2), q);
+    }
+    __syncthreads();
+
+    uint64_t *out = base;
+    const uint64_t *sub = nullptr, *addend = nullptr;
+    uint64_t cst = 0, cst_shoup = 0;
+    if (EPI != EPI_NONE) {
+        out = ep.out + blockIdx.y * ep.out_poly_stride + limb_off;
+        sub = ep.sub + blockIdx.y * ep.sub_poly_stride + limb_off;
+        if (EPI == EPI_SUB_MUL_ADD) addend = ep.addend + blockIdx.y * ep.out_poly_stride + limb_off;
+        cst = ep.cst[twr];
+        cst_shoup = ep.cst_shoup[twr];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t e = (i * kThreads + t) * 2;
+        ulonglong2 v;
+        v.x = lds[lds_row(e)];
+        v.y = lds[lds_row(e + 1)];
+        if (EPI != EPI_NONE) {
+            // (cx - NTT(delta)) * PInv mod q  (src/ntt/ntt_moddown.cu:209-214,
+            // include/uintmodmath.cuh:234-242); same shape for rescale (src/rns.cu:1138-1155)
+            const ulonglong2 s = *reinterpret_cast<const ulonglong2 *>(sub + e);
+            v.x = mul_shoup(csub(s.x + q - v.x, q), cst, cst_shoup, q);
+            v.y = mul_shoup(csub(s.y + q - v.y, q), cst, cst_shoup, q);
+            if (EPI == EPI_SUB_MUL_ADD) {
+                const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(addend + e);
+                v.x = csub(v.x + a.x, q);
+                v.y = csub(v.y + a.y, q);
+            }
+        }
+        *reinterpret_cast<ulonglong2 *>(out + e) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// inverse, row phase (first): stages m = N/2 .. 2^S1
+// ---------------------------------------------------------------------------------------------
+template <int S2, int RA>
+__global__ __launch_bounds__(kThreads) void intt_row_kernel(uint64_t *out, const uint64_t *in, size_t poly_stride,
+                                                            NttTables T, LimbMap lm) {
+    constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
+    __shared__ uint64_t lds[kLdsWords];
+    const uint32_t n = 1u << T.log_n, n1 = n >> S2, tiles = n >> 12;
+    const uint32_t li = blockIdx.x / tiles, ti = blockIdx.x % tiles;
+    uint32_t twr, tidx;
+    resolve_limb(lm, li, twr, tidx);
+    const size_t off = blockIdx.y * poly_stride + static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
+    const uint64_t *src = in + off;
+    uint64_t *dst = out + off;
+    const uint64_t q = T.mod[tidx].value, q2 = q << 1;
+    const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
+    const uint32_t t = threadIdx.x;
+
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t e = (i * kThreads + t) * 2;
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + e);
+        lds[lds_row(e)] = v.x;
+        lds[lds_row(e + 1)] = v.y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GD; g++) {
+        const uint32_t gid = t + kThreads * g, e0 = gid << RB;
+        const uint32_t ggid = ti * (kTile >> RB) + gid;
+        uint64_t x[1 << RB];
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) x[j] = lds[lds_row(e0 + j)];
+        const tw_t *twd = T.twD + static_cast<size_t>(tidx) * T.twD_stride +
+                          static_cast<size_t>(ggid >> 6) * (((1 << RB) - 1) * 64) + (ggid & 63);
+        gs_radix<RB, false>(x, LastPassTw<RB>{twd}, q, q2);
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) lds[lds_row(e0 + j)] = x[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GC; g++) {
+        const uint32_t gid = t + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;
+        uint64_t x[1 << RA];
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) x[j] = lds[lds_row(a * L + ((j << RB) | b_lo))];
+        gs_radix<RA, false>(x, CanonTw{tw, n1 + ti * RW + a}, q, q2);
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) dst[a * L + ((j << RB) | b_lo)] = x[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// inverse, column phase (last): stages m = 2^(S1-1) .. 1, N^-1, reduction to [0,q), optional scale
+// ---------------------------------------------------------------------------------------------
+template <int S1, int RA, int EPI>
+__global__ __launch_bounds__(kThreads) void intt_col_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm,
+                                                            Epilogue ep) {
+    constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
+    __shared__ uint64_t lds[kLdsWords];
+    const uint32_t n = 1u << T.log_n, n2 = n >> S1, tiles = n >> 12;
+    const uint32_t li = blockIdx.x / tiles, ti = blockIdx.x % tiles;
+    uint32_t twr, tidx;
+    resolve_limb(lm, li, twr, tidx);
+    uint64_t *base = data + blockIdx.y * poly_stride + static_cast<size_t>(twr) * n + ti * C;
+    const uint64_t q = T.mod[tidx].value, q2 = q << 1;
+    const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
+    const uint32_t t = threadIdx.x;
+
+#pragma unroll
+    for (int g = 0; g < GB; g++) {
+        const uint32_t gid = t + kThreads * g, c = gid % C, r_hi = gid / C;
+        uint64_t x[1 << RB];
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) x[j] = base[static_cast<size_t>((r_hi << RB) | j) * n2 + c];
+        gs_radix<RB, false>(x, CanonTw{tw, (1u << RA) + r_hi}, q, q2);
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) lds[lds_col<C, RB>((r_hi << RB) | j, c)] = x[j];
+    }
+    __syncthreads();
+    const uint64_t n_inv = T.n_inv[tidx], n_inv_shoup = T.n_inv_shoup[tidx];
+    uint64_t cst = 0, cst_shoup = 0;
+    if (EPI == EPI_SCALE) {
+        cst = ep.cst[twr];
+        cst_shoup = ep.cst_shoup[twr];
+    }
+#pragma unroll
+    for (int g = 0; g < GA; g++) {
+        const uint32_t gid = t + kThreads * g, c = gid % C, r_lo = gid / C;
+        uint64_t x[1 << RA];
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) x[j] = lds[lds_col<C, RB>((j << RB) | r_lo, c)];
+        gs_radix<RA, true>(x, CanonTw{tw, 1u}, q, q2, n_inv, n_inv_shoup);
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) {
+            uint64_t v = x[j];
+            // fused bconv phase 1 (src/ntt/ntt_modup.cu:212-318)
+            if (EPI == EPI_SCALE) v = mul_shoup(v, cst, cst_shoup, q);
+            base[static_cast<size_t>((j << RB) | r_lo) * n2 + c] = v;
+        }
+    }
+}
+
+}  // namespace pha

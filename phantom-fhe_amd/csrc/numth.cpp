@@ -1,0 +1,210 @@
+#include "numth.hpp"
+
+#include <algorithm>
+#include <map>
+
+namespace pha {
+
+uint64_t pow_mod(uint64_t base, uint64_t exp, uint64_t q) {
+    uint64_t acc = 1 % q;
+    base %= q;
+    for (; exp; exp >>= 1) {
+        if (exp & 1) acc = mul_mod(acc, base, q);
+        base = mul_mod(base, base, q);
+    }
+    return acc;
+}
+
+uint64_t inv_mod_prime(uint64_t a, uint64_t q) { return pow_mod(a % q, q - 2, q); }
+
+void barrett_ratio(uint64_t q, uint64_t ratio[2]) {
+    // long division of 2^128 by q, 64 bits at a time
+    const u128 b = static_cast<u128>(1) << 64;
+    const uint64_t hi = static_cast<uint64_t>(b / q);
+    const uint64_t r = static_cast<uint64_t>(b % q);
+    ratio[1] = hi;
+    ratio[0] = static_cast<uint64_t>((static_cast<u128>(r) << 64) / q);
+}
+
+bool is_prime_u64(uint64_t n) {
+    if (n < 2) return false;
+    for (uint64_t p : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+        if (n % p == 0) return n == p;
+    }
+    uint64_t d = n - 1;
+    int s = 0;
+    while (!(d & 1)) {
+        d >>= 1;
+        ++s;
+    }
+    // Sinclair's 7-base set is a deterministic Miller-Rabin test for all n < 2^64.
+    for (uint64_t a : {2ull, 325ull, 9375ull, 28178ull, 450775ull, 9780504ull, 1795265022ull}) {
+        uint64_t x = pow_mod(a, d, n);
+        if (x == 0 || x == 1 || x == n - 1) continue;
+        bool witness = true;
+        for (int i = 1; i < s && witness; ++i) {
+            x = mul_mod(x, x, n);
+            if (x == n - 1) witness = false;
+        }
+        if (witness) return false;
+    }
+    return true;
+}
+
+bool find_primes(uint64_t ntt_size, int bit_size, size_t count, std::vector<uint64_t> &out) {
+    out.clear();
+    if (bit_size < 2 || bit_size > 61) return false;
+    const uint64_t step = 2 * ntt_size;
+    const uint64_t top = uint64_t(1) << bit_size;
+    if (top <= step) return false;
+    const uint64_t floor_v = uint64_t(1) << (bit_size - 1);
+    for (uint64_t cand = top - step + 1; out.size() < count && cand > floor_v; cand -= step) {
+        if (is_prime_u64(cand)) out.push_back(cand);
+    }
+    return out.size() == count;
+}
+
+bool coeff_modulus_create(size_t n, const int *bit_sizes, size_t count, uint64_t *out) {
+    std::map<int, std::vector<uint64_t>> pool;
+    std::map<int, size_t> want;
+    for (size_t i = 0; i < count; ++i) ++want[bit_sizes[i]];
+    for (auto &kv : want) {
+        if (!find_primes(n, kv.first, kv.second, pool[kv.first])) return false;
+    }
+    // the generator found the primes in descending order; they are handed out from the back
+    for (size_t i = 0; i < count; ++i) {
+        auto &v = pool[bit_sizes[i]];
+        out[i] = v.back();
+        v.pop_back();
+    }
+    return true;
+}
+
+bool minimal_primitive_root(uint64_t degree, uint64_t q, uint64_t &root) {
+    if (degree < 2 || (q - 1) % degree) return false;
+    const uint64_t cofactor = (q - 1) / degree;
+    uint64_t r = 0;
+    for (uint64_t x = 2; x < 4096 && !r; ++x) {
+        const uint64_t cand = pow_mod(x, cofactor, q);
+        if (pow_mod(cand, degree / 2, q) == q - 1) r = cand;
+    }
+    if (!r) return false;
+    // every primitive root is an odd power of r: scan them all for the minimum
+    const uint64_t r2 = mul_mod(r, r, q);
+    uint64_t best = r, cur = r;
+    for (uint64_t i = 1; i < degree / 2; ++i) {
+        cur = mul_mod(cur, r2, q);
+        best = std::min(best, cur);
+    }
+    root = best;
+    return true;
+}
+
+bool build_limb_tables(int log_n, uint64_t q, LimbTables &t) {
+    const size_t n = size_t(1) << log_n;
+    t.q = q;
+    barrett_ratio(q, t.ratio);
+    if (!minimal_primitive_root(2 * n, q, t.psi)) return false;
+    const uint64_t psi_inv = inv_mod_prime(t.psi, q);
+    t.tw.assign(n, 0);
+    t.itw.assign(n, 0);
+    t.tw_shoup.assign(n, 0);
+    t.itw_shoup.assign(n, 0);
+    uint64_t f = 1, b = 1;
+    for (size_t e = 0; e < n; ++e) {
+        const uint32_t slot = bit_reverse(static_cast<uint32_t>(e), log_n);
+        t.tw[slot] = f;
+        t.itw[slot] = b;
+        f = mul_mod(f, t.psi, q);
+        b = mul_mod(b, psi_inv, q);
+    }
+    t.n_inv = inv_mod_prime(n % q, q);
+    t.n_inv_shoup = shoup(t.n_inv, q);
+    t.itw[1] = mul_mod(t.itw[1], t.n_inv, q);
+    for (size_t i = 0; i < n; ++i) {
+        t.tw_shoup[i] = shoup(t.tw[i], q);
+        t.itw_shoup[i] = shoup(t.itw[i], q);
+    }
+    return true;
+}
+
+void galois_permutation(int log_n, uint32_t galois_elt, uint32_t *table) {
+    const uint32_t n = 1u << log_n;
+    for (uint32_t i = 0; i < n; ++i) {
+        // output slot i holds the evaluation at psi^(2*brev(i)+1); X -> X^g moves it to the
+        // slot of exponent g*(2*brev(i)+1) mod 2n
+        const uint64_t odd = 2ull * bit_reverse(i, log_n) + 1;
+        const uint64_t mapped = (odd * galois_elt) & (2ull * n - 1);
+        table[i] = bit_reverse(static_cast<uint32_t>(mapped >> 1), log_n);
+    }
+}
+
+bool galois_elt_from_step(int log_n, int step, uint32_t &elt) {
+    const uint32_t n = 1u << log_n, m = 2 * n;
+    if (step == 0) {
+        elt = m - 1;
+        return true;
+    }
+    const uint32_t mag = static_cast<uint32_t>(step < 0 ? -static_cast<int64_t>(step) : step);
+    if (mag >= n / 2) return false;
+    uint32_t reps = step < 0 ? n / 2 - mag : mag;
+    uint64_t g = 1;
+    while (reps--) g = (g * 5) & (m - 1);
+    elt = static_cast<uint32_t>(g);
+    return true;
+}
+
+uint64_t product_mod_except(const uint64_t *base, size_t s, size_t e, size_t skip, uint64_t m) {
+    uint64_t acc = 1 % m;
+    for (size_t k = s; k < e; ++k) {
+        if (k == skip) continue;
+        acc = mul_mod(acc, base[k] % m, m);
+    }
+    return acc;
+}
+
+void build_level_constants(const std::vector<uint64_t> &moduli_QP, size_t size_P, size_t size_Ql, LevelConstants &lc) {
+    const size_t size_QP = moduli_QP.size(), size_Q = size_QP - size_P;
+    const uint64_t *Q = moduli_QP.data();
+    const uint64_t *P = Q + size_Q;
+    lc.size_Ql = size_Ql;
+    lc.alpha = size_P;
+    lc.beta = size_P ? (size_Ql + size_P - 1) / size_P : 0;
+
+    lc.inv_q_last_mod_q.resize(size_Ql ? size_Ql - 1 : 0);
+    for (size_t i = 0; i + 1 < size_Ql; ++i) lc.inv_q_last_mod_q[i] = inv_mod_prime(Q[size_Ql - 1] % Q[i], Q[i]);
+
+    lc.bigP_mod_q.resize(size_Ql);
+    lc.bigPInv_mod_q.resize(size_Ql);
+    for (size_t i = 0; i < size_Ql; ++i) {
+        lc.bigP_mod_q[i] = product_mod_except(P, 0, size_P, SIZE_MAX, Q[i]);
+        lc.bigPInv_mod_q[i] = inv_mod_prime(lc.bigP_mod_q[i], Q[i]);
+    }
+
+    // Q_l ∪ P as one list
+    std::vector<uint64_t> qlp(Q, Q + size_Ql);
+    qlp.insert(qlp.end(), P, P + size_P);
+
+    lc.partQlHatInv_mod_Ql_concat.resize(size_Ql);
+    lc.modup_matrix.assign(lc.beta, {});
+    for (size_t d = 0; d < lc.beta; ++d) {
+        const size_t s = d * size_P, e = std::min(s + size_P, size_Ql), len = e - s;
+        for (size_t i = s; i < e; ++i) {
+            lc.partQlHatInv_mod_Ql_concat[i] = inv_mod_prime(product_mod_except(Q, s, e, i, Q[i]), Q[i]);
+        }
+        auto &mat = lc.modup_matrix[d];
+        mat.reserve((qlp.size() - len) * len);
+        for (size_t j = 0; j < qlp.size(); ++j) {
+            if (j >= s && j < e) continue;
+            for (size_t i = s; i < e; ++i) mat.push_back(product_mod_except(Q, s, e, i, qlp[j]));
+        }
+    }
+
+    lc.PHatInv_mod_p.resize(size_P);
+    for (size_t k = 0; k < size_P; ++k) lc.PHatInv_mod_p[k] = inv_mod_prime(product_mod_except(P, 0, size_P, k, P[k]), P[k]);
+    lc.moddown_matrix.resize(size_Ql * size_P);
+    for (size_t j = 0; j < size_Ql; ++j)
+        for (size_t k = 0; k < size_P; ++k) lc.moddown_matrix[j * size_P + k] = product_mod_except(P, 0, size_P, k, Q[j]);
+}
+
+}  // namespace pha

@@ -1,0 +1,68 @@
+// Host-side number theory and table generation for the MI355X RNS hot path.
+// Mirrors the values produced by the reference's host generators (cited per function) so that
+// device tables are interchangeable with Phantom's DNTTTable / DRNSTool contents.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace pha {
+
+using u128 = unsigned __int128;
+
+inline uint64_t mul_mod(uint64_t a, uint64_t b, uint64_t q) { return static_cast<uint64_t>(static_cast<u128>(a) * b % q); }
+uint64_t pow_mod(uint64_t base, uint64_t exp, uint64_t q);
+uint64_t inv_mod_prime(uint64_t a, uint64_t q);
+// floor(w * 2^64 / q): Shoup companion (include/util/uintarithsmallmod.h:141-146)
+inline uint64_t shoup(uint64_t w, uint64_t q) { return static_cast<uint64_t>((static_cast<u128>(w) << 64) / q); }
+// floor(2^128 / q) -> {lo, hi} (src/modulus.cu:28-40)
+void barrett_ratio(uint64_t q, uint64_t ratio[2]);
+bool is_prime_u64(uint64_t n);
+// src/util/numth.cu:209-235
+bool find_primes(uint64_t ntt_size, int bit_size, size_t count, std::vector<uint64_t> &out);
+// src/modulus.cu:79-110
+bool coeff_modulus_create(size_t n, const int *bit_sizes, size_t count, uint64_t *out);
+// src/util/numth.cu:311-333: smallest primitive degree-th root of unity
+bool minimal_primitive_root(uint64_t degree, uint64_t q, uint64_t &root);
+
+inline uint32_t bit_reverse(uint32_t x, int bits) {
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+
+struct LimbTables {
+    uint64_t q = 0;
+    uint64_t ratio[2] = {0, 0};
+    uint64_t psi = 0;
+    uint64_t n_inv = 0, n_inv_shoup = 0;
+    std::vector<uint64_t> tw, tw_shoup, itw, itw_shoup;  // canonical (reference) order
+};
+// src/util/ntt.cu:11-56
+bool build_limb_tables(int log_n, uint64_t q, LimbTables &t);
+
+// include/galois.cuh:49-64
+void galois_permutation(int log_n, uint32_t galois_elt, uint32_t *table);
+// src/galois.cu:42-75; returns false for an out-of-range step
+bool galois_elt_from_step(int log_n, int step, uint32_t &elt);
+
+// prod_{k in [s,e), k != skip} base[k] mod m   (skip = SIZE_MAX for the full product)
+uint64_t product_mod_except(const uint64_t *base, size_t s, size_t e, size_t skip, uint64_t m);
+
+// DRNSTool level constants, src/rns.cu:60-192
+struct LevelConstants {
+    size_t size_Ql = 0, alpha = 0, beta = 0;
+    std::vector<uint64_t> inv_q_last_mod_q;            // [size_Ql-1]
+    std::vector<uint64_t> bigP_mod_q, bigPInv_mod_q;   // [size_Ql]
+    std::vector<uint64_t> partQlHatInv_mod_Ql_concat;  // [size_Ql]
+    // per digit d: matrix [obase = size_QlP - |digit|][ibase = |digit|] of QHat_{d,i} mod p_j
+    // (src/util/rns.cu:452-461), output order = Q_l ∪ P with the digit erased (src/rns.cu:157-163)
+    std::vector<std::vector<uint64_t>> modup_matrix;
+    // P -> Q_l: PHatInv_k mod p_k [alpha], matrix [size_Ql][alpha] of PHat_k mod q_j
+    std::vector<uint64_t> PHatInv_mod_p;
+    std::vector<uint64_t> moddown_matrix;
+};
+void build_level_constants(const std::vector<uint64_t> &moduli_QP, size_t size_P, size_t size_Ql, LevelConstants &lc);
+
+}  // namespace pha

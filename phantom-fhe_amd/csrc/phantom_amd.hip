@@ -1,0 +1,874 @@
+// C ABI of the MI355X-native RNS hot path (include/phantom_amd.h): context / table upload,
+// kernel launch sequences for the NTT family, hybrid key switch, Galois, rescale and tensor
+// product.  Host orchestration follows the dataflow of src/rns_bconv.cu, src/eval_key_switch.cu,
+// src/rns.cu:1157-1181 and src/evaluate.cu of the reference; kernels are in *_kernels.cuh.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/phantom_amd.h"
+#include "ntt_kernels.cuh"
+#include "numth.hpp"
+#include "rns_kernels.cuh"
+
+using namespace pha;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return fail(PHA_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+#define PHA_TRY(expr)             \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != PHA_OK) return rc_; \
+    } while (0)
+
+// NTT decomposition per log N: S1 column stages (first pass radix 2^RA1), S2 row stages
+struct NttPlan {
+    int s1, ra1, s2, ra2;
+};
+bool plan_for(int log_n, NttPlan &p) {
+    switch (log_n) {
+        case 12: p = {6, 3, 6, 3}; return true;
+        case 13: p = {6, 3, 7, 4}; return true;
+        case 14: p = {7, 4, 7, 4}; return true;
+        case 15: p = {7, 4, 8, 4}; return true;
+        case 16: p = {8, 4, 8, 4}; return true;
+        default: return false;
+    }
+}
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t count = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        count = 0;
+    }
+    hipError_t alloc(size_t n) {
+        release();
+        count = n;
+        return n ? hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)) : hipSuccess;
+    }
+    hipError_t upload(const std::vector<T> &h) {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+// value + Shoup companion, indexed by absolute limb
+struct ShoupVec {
+    DevBuf<uint64_t> v, s;
+    hipError_t upload(const std::vector<uint64_t> &vals, const uint64_t *moduli) {
+        std::vector<uint64_t> sh(vals.size());
+        for (size_t i = 0; i < vals.size(); i++) sh[i] = shoup(vals[i], moduli[i]);
+        hipError_t e = v.upload(vals);
+        return e != hipSuccess ? e : s.upload(sh);
+    }
+};
+
+// DRNSTool for one data level (src/rns.cu:11-192, CKKS subset)
+struct LevelTool {
+    size_t size_Ql = 0, beta = 0;
+    LevelConstants host;
+    ShoupVec inv_q_last, bigPInv, partHatInv, PHatInv;  // PHatInv indexed by P limb
+    std::vector<DevBuf<uint64_t>> modup_matrix;          // per digit
+    std::vector<DevBuf<uint32_t>> modup_obase_tidx;      // per digit: table index of each output limb
+    DevBuf<uint64_t> moddown_matrix;
+    DevBuf<uint32_t> moddown_obase_tidx;
+};
+
+}  // namespace
+
+struct pha_context {
+    int log_n = 0;
+    size_t n = 0, size_QP = 0, size_P = 0, size_Q = 0;
+    NttPlan plan{};
+    std::vector<uint64_t> moduli;
+    std::vector<LimbTables> host_tables;
+    DevBuf<DModulus> d_mod;
+    DevBuf<tw_t> d_tw, d_itw, d_twD, d_itwD;
+    DevBuf<uint64_t> d_n_inv, d_n_inv_shoup;
+    uint32_t twD_stride = 0;
+    std::map<size_t, std::unique_ptr<LevelTool>> levels;
+    std::map<uint32_t, std::unique_ptr<DevBuf<uint32_t>>> galois_tables;
+    DevBuf<uint64_t> workspace;
+
+    NttTables fwd_tables() const {
+        return NttTables{d_mod.p, d_tw.p, d_twD.p, d_n_inv.p, d_n_inv_shoup.p, static_cast<uint32_t>(log_n), twD_stride};
+    }
+    NttTables inv_tables() const {
+        return NttTables{d_mod.p, d_itw.p, d_itwD.p, d_n_inv.p, d_n_inv_shoup.p, static_cast<uint32_t>(log_n), twD_stride};
+    }
+};
+
+namespace {
+
+int ensure_workspace(pha_context *ctx, size_t words, uint64_t **out) {
+    if (ctx->workspace.count < words) {
+        // the old buffer may still be in use by enqueued kernels
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(ctx->workspace.alloc(words));
+    }
+    *out = ctx->workspace.p;
+    return PHA_OK;
+}
+
+int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(PHA_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return PHA_OK;
+}
+
+// ---- table upload -------------------------------------------------------------------------
+void interleave(const std::vector<uint64_t> &w, const std::vector<uint64_t> &ws, tw_t *dst) {
+    for (size_t i = 0; i < w.size(); i++) dst[i] = tw_t{w[i], ws[i]};
+}
+
+// last-pass order: [(ggid >> 6)][slot][ggid & 63], record = tw[((n >> rb) + ggid) << s | jb]
+void last_pass_order(const tw_t *canon, size_t n, int rb, tw_t *dst) {
+    const size_t groups = n >> rb, nslot = (size_t(1) << rb) - 1;
+    for (size_t g = 0; g < groups; g++) {
+        for (int s = 0; s < rb; s++) {
+            for (size_t jb = 0; jb < (size_t(1) << s); jb++) {
+                const size_t slot = (size_t(1) << s) - 1 + jb;
+                dst[((g >> 6) * nslot + slot) * 64 + (g & 63)] = canon[(((n >> rb) + g) << s) + jb];
+            }
+        }
+    }
+}
+
+int upload_tables(pha_context *ctx) {
+    const size_t n = ctx->n, L = ctx->size_QP;
+    const int rb = ctx->plan.s2 - ctx->plan.ra2;
+    const size_t stride = (n >> rb) * ((size_t(1) << rb) - 1);
+    ctx->twD_stride = static_cast<uint32_t>(stride);
+    std::vector<tw_t> tw(L * n), itw(L * n), twD(L * stride), itwD(L * stride);
+    std::vector<DModulus> mods(L);
+    std::vector<uint64_t> ninv(L), ninv_s(L);
+    for (size_t l = 0; l < L; l++) {
+        const LimbTables &t = ctx->host_tables[l];
+        interleave(t.tw, t.tw_shoup, tw.data() + l * n);
+        interleave(t.itw, t.itw_shoup, itw.data() + l * n);
+        last_pass_order(tw.data() + l * n, n, rb, twD.data() + l * stride);
+        last_pass_order(itw.data() + l * n, n, rb, itwD.data() + l * stride);
+        mods[l] = DModulus{t.q, t.ratio[0], t.ratio[1]};
+        ninv[l] = t.n_inv;
+        ninv_s[l] = t.n_inv_shoup;
+    }
+    HIP_TRY(ctx->d_tw.upload(tw));
+    HIP_TRY(ctx->d_itw.upload(itw));
+    HIP_TRY(ctx->d_twD.upload(twD));
+    HIP_TRY(ctx->d_itwD.upload(itwD));
+    HIP_TRY(ctx->d_mod.upload(mods));
+    HIP_TRY(ctx->d_n_inv.upload(ninv));
+    HIP_TRY(ctx->d_n_inv_shoup.upload(ninv_s));
+    return PHA_OK;
+}
+
+// ---- NTT launchers ------------------------------------------------------------------------
+struct NttRange {
+    LimbMap lm;
+    uint32_t active;  // limbs actually transformed
+};
+
+int make_range(const pha_context *ctx, size_t count, size_t start, size_t size_QP, size_t size_P, size_t excl_s,
+               size_t excl_e, NttRange &r) {
+    if (count == 0) return fail(PHA_ERR_INVALID_ARGUMENT, "coeff_modulus_size must be positive");
+    if (size_P) {
+        if (size_QP != ctx->size_QP || size_P > count || size_P > size_QP)
+            return fail(PHA_ERR_INVALID_ARGUMENT, "special modulus range does not match the context");
+        if (start + count - size_P > size_QP - size_P)
+            return fail(PHA_ERR_INVALID_ARGUMENT, "limb range exceeds the modulus chain");
+    } else if (start + count > ctx->size_QP) {
+        return fail(PHA_ERR_INVALID_ARGUMENT, "limb range exceeds the modulus chain");
+    }
+    uint32_t len = 0;
+    if (excl_e > excl_s) {
+        if (excl_s < start || excl_e > start + count)
+            return fail(PHA_ERR_INVALID_ARGUMENT, "Excluded range in NTT is invalid.");
+        len = static_cast<uint32_t>(excl_e - excl_s);
+    } else {
+        excl_s = excl_e = 0;
+    }
+    r.lm = LimbMap{static_cast<uint32_t>(start), static_cast<uint32_t>(count), static_cast<uint32_t>(size_QP),
+                   static_cast<uint32_t>(size_P), static_cast<uint32_t>(excl_s), static_cast<uint32_t>(excl_e)};
+    r.active = static_cast<uint32_t>(count) - len;
+    return PHA_OK;
+}
+
+template <int S, int RA>
+void launch_fcol(dim3 grid, hipStream_t st, uint64_t *data, size_t ps, const NttTables &T, const LimbMap &lm) {
+    hipLaunchKernelGGL((fntt_col_kernel<S, RA>), grid, dim3(kThreads), 0, st, data, ps, T, lm);
+}
+template <int S, int RA>
+void launch_frow(int epi, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, const NttTables &T, const LimbMap &lm,
+                 const Epilogue &ep) {
+    switch (epi) {
+        case EPI_SUB_MUL:
+            hipLaunchKernelGGL((fntt_row_kernel<S, RA, EPI_SUB_MUL>), grid, dim3(kThreads), 0, st, data, ps, T, lm, ep);
+            break;
+        case EPI_SUB_MUL_ADD:
+            hipLaunchKernelGGL((fntt_row_kernel<S, RA, EPI_SUB_MUL_ADD>), grid, dim3(kThreads), 0, st, data, ps, T, lm, ep);
+            break;
+        default:
+            hipLaunchKernelGGL((fntt_row_kernel<S, RA, EPI_NONE>), grid, dim3(kThreads), 0, st, data, ps, T, lm, ep);
+    }
+}
+template <int S, int RA>
+void launch_irow(dim3 grid, hipStream_t st, uint64_t *out, const uint64_t *in, size_t ps, const NttTables &T,
+                 const LimbMap &lm) {
+    hipLaunchKernelGGL((intt_row_kernel<S, RA>), grid, dim3(kThreads), 0, st, out, in, ps, T, lm);
+}
+template <int S, int RA>
+void launch_icol(int epi, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, const NttTables &T, const LimbMap &lm,
+                 const Epilogue &ep) {
+    if (epi == EPI_SCALE)
+        hipLaunchKernelGGL((intt_col_kernel<S, RA, EPI_SCALE>), grid, dim3(kThreads), 0, st, data, ps, T, lm, ep);
+    else
+        hipLaunchKernelGGL((intt_col_kernel<S, RA, EPI_NONE>), grid, dim3(kThreads), 0, st, data, ps, T, lm, ep);
+}
+
+#define DISPATCH_S(S, RA, CALL6, CALL7, CALL8) \
+    switch (S) {                               \
+        case 6: CALL6; break;                  \
+        case 7: CALL7; break;                  \
+        default: CALL8; break;                 \
+    }
+
+int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stride, const NttRange &r, int epi,
+                const Epilogue &ep, hipStream_t st) {
+    if (!r.active || !polys) return PHA_OK;
+    const dim3 grid(r.active * static_cast<uint32_t>(ctx->n >> 12), static_cast<uint32_t>(polys));
+    const NttTables T = ctx->fwd_tables();
+    DISPATCH_S(ctx->plan.s1, 0, (launch_fcol<6, 3>(grid, st, data, poly_stride, T, r.lm)),
+               (launch_fcol<7, 4>(grid, st, data, poly_stride, T, r.lm)),
+               (launch_fcol<8, 4>(grid, st, data, poly_stride, T, r.lm)));
+    DISPATCH_S(ctx->plan.s2, 0, (launch_frow<6, 3>(epi, grid, st, data, poly_stride, T, r.lm, ep)),
+               (launch_frow<7, 4>(epi, grid, st, data, poly_stride, T, r.lm, ep)),
+               (launch_frow<8, 4>(epi, grid, st, data, poly_stride, T, r.lm, ep)));
+    return check_launch("forward NTT");
+}
+
+int ntt_backward(pha_context *ctx, uint64_t *out, const uint64_t *in, size_t polys, size_t poly_stride,
+                 const NttRange &r, int epi, const Epilogue &ep, hipStream_t st) {
+    if (!r.active || !polys) return PHA_OK;
+    const dim3 grid(r.active * static_cast<uint32_t>(ctx->n >> 12), static_cast<uint32_t>(polys));
+    const NttTables T = ctx->inv_tables();
+    DISPATCH_S(ctx->plan.s2, 0, (launch_irow<6, 3>(grid, st, out, in, poly_stride, T, r.lm)),
+               (launch_irow<7, 4>(grid, st, out, in, poly_stride, T, r.lm)),
+               (launch_irow<8, 4>(grid, st, out, in, poly_stride, T, r.lm)));
+    DISPATCH_S(ctx->plan.s1, 0, (launch_icol<6, 3>(epi, grid, st, out, poly_stride, T, r.lm, ep)),
+               (launch_icol<7, 4>(epi, grid, st, out, poly_stride, T, r.lm, ep)),
+               (launch_icol<8, 4>(epi, grid, st, out, poly_stride, T, r.lm, ep)));
+    return check_launch("inverse NTT");
+}
+
+// ---- level tools ---------------------------------------------------------------------------
+int get_level(pha_context *ctx, size_t chain_index, LevelTool **out) {
+    if (chain_index < 1 || chain_index > ctx->size_Q)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "chain_index %zu out of range [1, %zu]", chain_index, ctx->size_Q);
+    if (ctx->size_P == 0) return fail(PHA_ERR_LOGIC, "context has no special modulus");
+    const size_t size_Ql = ctx->size_Q - (chain_index - 1);
+    auto it = ctx->levels.find(size_Ql);
+    if (it != ctx->levels.end()) {
+        *out = it->second.get();
+        return PHA_OK;
+    }
+    auto lt = std::make_unique<LevelTool>();
+    lt->size_Ql = size_Ql;
+    build_level_constants(ctx->moduli, ctx->size_P, size_Ql, lt->host);
+    lt->beta = lt->host.beta;
+    const uint64_t *Q = ctx->moduli.data();
+    const uint64_t *P = Q + ctx->size_Q;
+    if (size_Ql > 1) HIP_TRY(lt->inv_q_last.upload(lt->host.inv_q_last_mod_q, Q));
+    HIP_TRY(lt->bigPInv.upload(lt->host.bigPInv_mod_q, Q));
+    HIP_TRY(lt->partHatInv.upload(lt->host.partQlHatInv_mod_Ql_concat, Q));
+    HIP_TRY(lt->PHatInv.upload(lt->host.PHatInv_mod_p, P));
+    lt->modup_matrix.resize(lt->beta);
+    lt->modup_obase_tidx.resize(lt->beta);
+    for (size_t d = 0; d < lt->beta; d++) {
+        const size_t s = d * ctx->size_P, e = std::min(s + ctx->size_P, size_Ql);
+        std::vector<uint32_t> tidx;
+        for (size_t j = 0; j < size_Ql + ctx->size_P; j++) {
+            if (j >= s && j < e) continue;
+            tidx.push_back(static_cast<uint32_t>(j < size_Ql ? j : ctx->size_Q + (j - size_Ql)));
+        }
+        HIP_TRY(lt->modup_matrix[d].upload(lt->host.modup_matrix[d]));
+        HIP_TRY(lt->modup_obase_tidx[d].upload(tidx));
+    }
+    std::vector<uint32_t> tidx(size_Ql);
+    for (size_t j = 0; j < size_Ql; j++) tidx[j] = static_cast<uint32_t>(j);
+    HIP_TRY(lt->moddown_matrix.upload(lt->host.moddown_matrix));
+    HIP_TRY(lt->moddown_obase_tidx.upload(tidx));
+    *out = lt.get();
+    ctx->levels[size_Ql] = std::move(lt);
+    return PHA_OK;
+}
+
+int launch_bconv(pha_context *ctx, uint64_t *dst, const uint64_t *y, const uint64_t *matrix, const uint32_t *obase_tidx,
+                 uint32_t ibase, uint32_t obase, uint32_t skip_start, uint32_t skip_len, hipStream_t st) {
+    const uint32_t n = static_cast<uint32_t>(ctx->n);
+    // enough workgroups to fill 256 CUs a few times over without re-reading the inputs too often
+    uint32_t lpb = std::max<uint32_t>(1, obase / 8);
+    const dim3 grid(n / 256, (obase + lpb - 1) / lpb);
+    const DModulus *mod = ctx->d_mod.p;
+#define BCONV_CASE(IB)                                                                                          \
+    case IB:                                                                                                    \
+        hipLaunchKernelGGL((bconv_matmul_kernel<IB>), grid, dim3(256), 0, st, dst, y, matrix, mod, obase_tidx, \
+                           obase, lpb, n, skip_start, skip_len);                                               \
+        break;
+    switch (ibase) {
+        BCONV_CASE(1) BCONV_CASE(2) BCONV_CASE(3) BCONV_CASE(4) BCONV_CASE(5) BCONV_CASE(6) BCONV_CASE(7) BCONV_CASE(8)
+        BCONV_CASE(9) BCONV_CASE(10) BCONV_CASE(11) BCONV_CASE(12) BCONV_CASE(13) BCONV_CASE(14) BCONV_CASE(15)
+        BCONV_CASE(16)
+        default:
+            hipLaunchKernelGGL(bconv_matmul_generic_kernel, grid, dim3(256), 0, st, dst, y, matrix, mod, obase_tidx,
+                               ibase, obase, lpb, n, skip_start, skip_len);
+    }
+#undef BCONV_CASE
+    return check_launch("bconv_matmul");
+}
+
+// DRNSTool::modup (src/rns_bconv.cu:530-628), t_cks = scratch [size_Ql][n]
+int do_modup(pha_context *ctx, LevelTool *lt, uint64_t *dst, const uint64_t *cks, uint64_t *t_cks, hipStream_t st) {
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, alpha = ctx->size_P, size_QlP = size_Ql + alpha;
+    NttRange r;
+    PHA_TRY(make_range(ctx, size_Ql, 0, 0, 0, 0, 0, r));
+    Epilogue ep{};
+    if (alpha == 1) {
+        PHA_TRY(ntt_backward(ctx, t_cks, cks, 1, 0, r, EPI_NONE, ep, st));
+        hipLaunchKernelGGL(modup_single_p_kernel, dim3(static_cast<uint32_t>(n / 256), static_cast<uint32_t>(lt->beta)),
+                           dim3(256), 0, st, dst, cks, t_cks, ctx->d_mod.p, static_cast<uint32_t>(size_Ql),
+                           static_cast<uint32_t>(ctx->size_Q), static_cast<uint32_t>(n));
+        PHA_TRY(check_launch("modup_single_p"));
+    } else {
+        ep.cst = lt->partHatInv.v.p;
+        ep.cst_shoup = lt->partHatInv.s.p;
+        PHA_TRY(ntt_backward(ctx, t_cks, cks, 1, 0, r, EPI_SCALE, ep, st));
+        for (size_t d = 0; d < lt->beta; d++) {
+            const size_t s = d * alpha, e = std::min(s + alpha, size_Ql), len = e - s;
+            uint64_t *part = dst + d * size_QlP * n;
+            HIP_TRY(hipMemcpyAsync(part + s * n, cks + s * n, len * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+            PHA_TRY(launch_bconv(ctx, part, t_cks + s * n, lt->modup_matrix[d].p, lt->modup_obase_tidx[d].p,
+                                 static_cast<uint32_t>(len), static_cast<uint32_t>(size_QlP - len),
+                                 static_cast<uint32_t>(s), static_cast<uint32_t>(len), st));
+        }
+    }
+    for (size_t d = 0; d < lt->beta; d++) {
+        const size_t s = d * alpha, e = std::min(s + alpha, size_Ql);
+        NttRange rr;
+        PHA_TRY(make_range(ctx, size_QlP, 0, ctx->size_QP, alpha, s, e, rr));
+        PHA_TRY(ntt_forward(ctx, dst + d * size_QlP * n, 1, 0, rr, EPI_NONE, Epilogue{}, st));
+    }
+    return PHA_OK;
+}
+
+int do_inner_prod(pha_context *ctx, LevelTool *lt, uint64_t *cx, const uint64_t *t_mod_up, const uint64_t *const *evks,
+                  hipStream_t st) {
+    const uint32_t n = static_cast<uint32_t>(ctx->n);
+    const uint32_t size_QlP = static_cast<uint32_t>(lt->size_Ql + ctx->size_P);
+    hipLaunchKernelGGL(key_switch_inner_prod_kernel, dim3(size_QlP * (n / 512)), dim3(256), 0, st, cx, t_mod_up, evks,
+                       ctx->d_mod.p, n, static_cast<uint32_t>(ctx->size_QP), size_QlP,
+                       static_cast<uint32_t>(ctx->size_Q), static_cast<uint32_t>(lt->size_Ql),
+                       static_cast<uint32_t>(lt->beta));
+    return check_launch("key_switch_inner_prod");
+}
+
+// DRNSTool::moddown_from_NTT (src/rns_bconv.cu:776-828), delta = scratch [size_Ql][n].
+// addend != nullptr fuses add_to_ct: ct_i = addend + (cx - NTT(delta)) * PInv
+int do_moddown(pha_context *ctx, LevelTool *lt, uint64_t *ct_i, uint64_t *cx_i, uint64_t *delta,
+               const uint64_t *addend, hipStream_t st) {
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, alpha = ctx->size_P;
+    NttRange rp;
+    PHA_TRY(make_range(ctx, alpha, size_Ql, ctx->size_QP, alpha, 0, 0, rp));
+    uint64_t *cp = cx_i + size_Ql * n;
+    if (alpha == 1) {
+        PHA_TRY(ntt_backward(ctx, cx_i, cx_i, 1, 0, rp, EPI_NONE, Epilogue{}, st));
+        hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(static_cast<uint32_t>(n / 512), 1), dim3(256), 0, st, delta,
+                           cp, ctx->d_mod.p, static_cast<uint32_t>(size_Ql), static_cast<uint32_t>(n), size_t(0),
+                           size_t(0));
+        PHA_TRY(check_launch("reduce_single_limb"));
+    } else {
+        // INTT fused with bconv phase 1 (x PHatInv mod p_k); constants indexed by buffer limb
+        Epilogue ep{};
+        ep.cst = lt->PHatInv.v.p - size_Ql;
+        ep.cst_shoup = lt->PHatInv.s.p - size_Ql;
+        PHA_TRY(ntt_backward(ctx, cx_i, cx_i, 1, 0, rp, EPI_SCALE, ep, st));
+        PHA_TRY(launch_bconv(ctx, delta, cp, lt->moddown_matrix.p, lt->moddown_obase_tidx.p, static_cast<uint32_t>(alpha),
+                             static_cast<uint32_t>(size_Ql), static_cast<uint32_t>(size_Ql), 0, st));
+    }
+    NttRange rq;
+    PHA_TRY(make_range(ctx, size_Ql, 0, 0, 0, 0, 0, rq));
+    Epilogue ep{};
+    ep.out = ct_i;
+    ep.sub = cx_i;
+    ep.addend = addend;
+    ep.cst = lt->bigPInv.v.p;
+    ep.cst_shoup = lt->bigPInv.s.p;
+    return ntt_forward(ctx, delta, 1, 0, rq, addend ? EPI_SUB_MUL_ADD : EPI_SUB_MUL, ep, st);
+}
+
+int do_keyswitch(pha_context *ctx, LevelTool *lt, uint64_t *ct, const uint64_t *c2, const uint64_t *const *evks,
+                 hipStream_t st) {
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, size_QlP = size_Ql + ctx->size_P;
+    uint64_t *ws;
+    PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + size_Ql) * n, &ws));
+    uint64_t *t_mod_up = ws, *cx = t_mod_up + lt->beta * size_QlP * n, *scratch = cx + 2 * size_QlP * n;
+    PHA_TRY(do_modup(ctx, lt, t_mod_up, c2, scratch, st));
+    PHA_TRY(do_inner_prod(ctx, lt, cx, t_mod_up, evks, st));
+    for (int i = 0; i < 2; i++) {
+        // moddown + add_to_ct fused into the NTT epilogue (src/eval_key_switch.cu:157-177)
+        uint64_t *ct_i = ct + i * size_Ql * n;
+        PHA_TRY(do_moddown(ctx, lt, ct_i, cx + i * size_QlP * n, scratch, ct_i, st));
+    }
+    return PHA_OK;
+}
+
+int do_rescale(pha_context *ctx, LevelTool *lt, const uint64_t *src, const uint64_t *last_coeff, size_t last_stride,
+               size_t cipher_size, uint64_t *dst, hipStream_t st) {
+    // last_coeff[p * last_stride ...]: INTT'ed last limb of poly p
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, next = size_Ql - 1;
+    hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(static_cast<uint32_t>(n / 512), static_cast<uint32_t>(cipher_size)),
+                       dim3(256), 0, st, dst, last_coeff, ctx->d_mod.p, static_cast<uint32_t>(next),
+                       static_cast<uint32_t>(n), next * n, last_stride);
+    PHA_TRY(check_launch("reduce_single_limb"));
+    NttRange r;
+    PHA_TRY(make_range(ctx, next, 0, 0, 0, 0, 0, r));
+    Epilogue ep{};
+    ep.out = dst;
+    ep.sub = src;
+    ep.cst = lt->inv_q_last.v.p;
+    ep.cst_shoup = lt->inv_q_last.s.p;
+    ep.out_poly_stride = next * n;
+    ep.sub_poly_stride = size_Ql * n;
+    return ntt_forward(ctx, dst, cipher_size, next * n, r, EPI_SUB_MUL, ep, st);
+}
+
+int get_galois_table(pha_context *ctx, uint32_t elt, const uint32_t **out) {
+    if (!(elt & 1) || elt >= 2 * ctx->n) return fail(PHA_ERR_INVALID_ARGUMENT, "Galois element is not valid");
+    auto it = ctx->galois_tables.find(elt);
+    if (it == ctx->galois_tables.end()) {
+        std::vector<uint32_t> h(ctx->n);
+        galois_permutation(ctx->log_n, elt, h.data());
+        auto buf = std::make_unique<DevBuf<uint32_t>>();
+        HIP_TRY(buf->upload(h));
+        it = ctx->galois_tables.emplace(elt, std::move(buf)).first;
+    }
+    *out = it->second->p;
+    return PHA_OK;
+}
+
+int do_galois(pha_context *ctx, const uint64_t *operand, size_t limbs, const uint32_t *perm, uint64_t *result,
+              hipStream_t st) {
+    const uint32_t n = static_cast<uint32_t>(ctx->n);
+    hipLaunchKernelGGL(apply_galois_ntt_kernel, dim3(static_cast<uint32_t>(limbs) * (n / 512)), dim3(256), 0, st, result,
+                       operand, perm, n);
+    return check_launch("apply_galois_ntt");
+}
+
+inline hipStream_t as_stream(pha_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char *pha_last_error(void) { return g_last_error.c_str(); }
+const char *pha_version(void) { return "phantom-fhe_amd 0.1 (gfx950)"; }
+
+int pha_coeff_modulus_create(size_t poly_modulus_degree, const int *bit_sizes, size_t count, uint64_t *out_moduli) {
+    if (!bit_sizes || !out_moduli) return fail(PHA_ERR_INVALID_ARGUMENT, "null argument");
+    if (poly_modulus_degree < 2 || (poly_modulus_degree & (poly_modulus_degree - 1)) || poly_modulus_degree > 131072)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "poly_modulus_degree is invalid");
+    for (size_t i = 0; i < count; i++)
+        if (bit_sizes[i] < 2 || bit_sizes[i] > 60) return fail(PHA_ERR_INVALID_ARGUMENT, "bit_sizes is invalid");
+    if (!coeff_modulus_create(poly_modulus_degree, bit_sizes, count, out_moduli))
+        return fail(PHA_ERR_LOGIC, "failed to find enough qualifying primes");
+    return PHA_OK;
+}
+
+int pha_host_ntt_tables(int log_n, uint64_t modulus, uint64_t *tw, uint64_t *tw_shoup, uint64_t *itw, uint64_t *itw_shoup,
+                        uint64_t *n_inv, uint64_t *n_inv_shoup) {
+    if (log_n < 1 || log_n > 17) return fail(PHA_ERR_INVALID_ARGUMENT, "log_n out of range");
+    LimbTables t;
+    if (modulus >> 61 || !is_prime_u64(modulus) || !build_limb_tables(log_n, modulus, t))
+        return fail(PHA_ERR_INVALID_ARGUMENT, "invalid modulus in try_minimal_primitive_root");
+    const size_t bytes = (size_t(1) << log_n) * sizeof(uint64_t);
+    if (tw) memcpy(tw, t.tw.data(), bytes);
+    if (tw_shoup) memcpy(tw_shoup, t.tw_shoup.data(), bytes);
+    if (itw) memcpy(itw, t.itw.data(), bytes);
+    if (itw_shoup) memcpy(itw_shoup, t.itw_shoup.data(), bytes);
+    if (n_inv) *n_inv = t.n_inv;
+    if (n_inv_shoup) *n_inv_shoup = t.n_inv_shoup;
+    return PHA_OK;
+}
+
+int pha_host_barrett_ratio(uint64_t modulus, uint64_t ratio[2]) {
+    if (modulus < 2 || modulus >> 61) return fail(PHA_ERR_INVALID_ARGUMENT, "value can be at most 61-bit and cannot be 1");
+    barrett_ratio(modulus, ratio);
+    return PHA_OK;
+}
+
+int pha_host_galois_table(int log_n, uint32_t galois_elt, uint32_t *table) {
+    if (log_n < 1 || log_n > 17 || !table) return fail(PHA_ERR_INVALID_ARGUMENT, "coeff_count_power out of range");
+    if (!(galois_elt & 1) || galois_elt >= (2u << log_n)) return fail(PHA_ERR_INVALID_ARGUMENT, "Galois element is not valid");
+    galois_permutation(log_n, galois_elt, table);
+    return PHA_OK;
+}
+
+int pha_galois_elt_from_step(int log_n, int step, uint32_t *out_elt) {
+    if (log_n < 1 || log_n > 17 || !out_elt) return fail(PHA_ERR_INVALID_ARGUMENT, "coeff_count_power out of range");
+    if (!galois_elt_from_step(log_n, step, *out_elt)) return fail(PHA_ERR_INVALID_ARGUMENT, "step count too large");
+    return PHA_OK;
+}
+
+int pha_host_level_constants(const uint64_t *moduli_QP, size_t size_QP, size_t size_P, size_t size_Ql,
+                             uint64_t *inv_q_last_mod_q, uint64_t *bigP_mod_q, uint64_t *bigPInv_mod_q,
+                             uint64_t *partQlHatInv_mod_Ql_concat) {
+    if (!moduli_QP || size_P == 0 || size_P >= size_QP || size_Ql == 0 || size_Ql > size_QP - size_P)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "RNSBase is invalid");
+    LevelConstants lc;
+    build_level_constants(std::vector<uint64_t>(moduli_QP, moduli_QP + size_QP), size_P, size_Ql, lc);
+    auto put = [](uint64_t *dst, const std::vector<uint64_t> &v) {
+        if (dst && !v.empty()) memcpy(dst, v.data(), v.size() * sizeof(uint64_t));
+    };
+    put(inv_q_last_mod_q, lc.inv_q_last_mod_q);
+    put(bigP_mod_q, lc.bigP_mod_q);
+    put(bigPInv_mod_q, lc.bigPInv_mod_q);
+    put(partQlHatInv_mod_Ql_concat, lc.partQlHatInv_mod_Ql_concat);
+    return PHA_OK;
+}
+
+int pha_context_create(int log_n, const uint64_t *moduli_QP, size_t size_QP, size_t size_P, pha_context **out) {
+    if (!moduli_QP || !out) return fail(PHA_ERR_INVALID_ARGUMENT, "null argument");
+    NttPlan plan;
+    if (!plan_for(log_n, plan))
+        return fail(PHA_ERR_INVALID_ARGUMENT, "unsupported polynomial degree when selecting sample size");
+    if (size_QP == 0 || size_QP > 64 || size_P >= size_QP) return fail(PHA_ERR_INVALID_ARGUMENT, "coeff_modulus is invalid");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PHA_ERR_NO_DEVICE, "no HIP device available");
+    auto ctx = std::make_unique<pha_context>();
+    ctx->log_n = log_n;
+    ctx->n = size_t(1) << log_n;
+    ctx->size_QP = size_QP;
+    ctx->size_P = size_P;
+    ctx->size_Q = size_QP - size_P;
+    ctx->plan = plan;
+    ctx->moduli.assign(moduli_QP, moduli_QP + size_QP);
+    ctx->host_tables.resize(size_QP);
+    for (size_t i = 0; i < size_QP; i++) {
+        for (size_t j = 0; j < i; j++)
+            if (moduli_QP[i] == moduli_QP[j]) return fail(PHA_ERR_INVALID_ARGUMENT, "coeff_modulus is not coprime");
+        if (moduli_QP[i] >> 61 || !is_prime_u64(moduli_QP[i]) ||
+            !build_limb_tables(log_n, moduli_QP[i], ctx->host_tables[i]))
+            return fail(PHA_ERR_INVALID_ARGUMENT, "invalid modulus in try_minimal_primitive_root");
+    }
+    PHA_TRY(upload_tables(ctx.get()));
+    *out = ctx.release();
+    return PHA_OK;
+}
+
+void pha_context_destroy(pha_context *ctx) {
+    if (!ctx) return;
+    (void)hipDeviceSynchronize();
+    delete ctx;
+}
+
+size_t pha_context_n(const pha_context *ctx) { return ctx ? ctx->n : 0; }
+size_t pha_context_size_QP(const pha_context *ctx) { return ctx ? ctx->size_QP : 0; }
+size_t pha_context_size_P(const pha_context *ctx) { return ctx ? ctx->size_P : 0; }
+
+int pha_context_get_moduli(const pha_context *ctx, uint64_t *out_host) {
+    if (!ctx || !out_host) return fail(PHA_ERR_INVALID_ARGUMENT, "null argument");
+    memcpy(out_host, ctx->moduli.data(), ctx->size_QP * sizeof(uint64_t));
+    return PHA_OK;
+}
+
+int pha_context_get_table(const pha_context *ctx, size_t limb, int which, uint64_t *out_host) {
+    if (!ctx || !out_host || limb >= ctx->size_QP || which < 0 || which > 3)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "invalid table request");
+    // read back from the device copy so that the getter checks what the kernels actually use
+    const tw_t *src = (which < 2 ? ctx->d_tw.p : ctx->d_itw.p) + limb * ctx->n;
+    std::vector<tw_t> h(ctx->n);
+    HIP_TRY(hipMemcpy(h.data(), src, ctx->n * sizeof(tw_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < ctx->n; i++) out_host[i] = (which & 1) ? h[i].y : h[i].x;
+    return PHA_OK;
+}
+
+#define REQUIRE_CTX(ptr_ok)                                                          \
+    if (!ctx || !(ptr_ok)) return fail(PHA_ERR_INVALID_ARGUMENT, "null argument")
+
+int pha_nwt_2d_radix8_forward_inplace(pha_context *ctx, uint64_t *inout, size_t count, size_t start, pha_stream_t stream) {
+    REQUIRE_CTX(inout);
+    NttRange r;
+    PHA_TRY(make_range(ctx, count, start, 0, 0, 0, 0, r));
+    return ntt_forward(ctx, inout, 1, 0, r, EPI_NONE, Epilogue{}, as_stream(stream));
+}
+
+int pha_nwt_2d_radix8_backward_inplace(pha_context *ctx, uint64_t *inout, size_t count, size_t start, pha_stream_t stream) {
+    REQUIRE_CTX(inout);
+    NttRange r;
+    PHA_TRY(make_range(ctx, count, start, 0, 0, 0, 0, r));
+    return ntt_backward(ctx, inout, inout, 1, 0, r, EPI_NONE, Epilogue{}, as_stream(stream));
+}
+
+int pha_nwt_2d_radix8_backward(pha_context *ctx, uint64_t *out, const uint64_t *in, size_t count, size_t start,
+                               pha_stream_t stream) {
+    REQUIRE_CTX(out && in);
+    NttRange r;
+    PHA_TRY(make_range(ctx, count, start, 0, 0, 0, 0, r));
+    return ntt_backward(ctx, out, in, 1, 0, r, EPI_NONE, Epilogue{}, as_stream(stream));
+}
+
+int pha_nwt_2d_radix8_backward_scale(pha_context *ctx, uint64_t *out, const uint64_t *in, size_t count, size_t start,
+                                     const uint64_t *scale, const uint64_t *scale_shoup, pha_stream_t stream) {
+    REQUIRE_CTX(out && in && scale && scale_shoup);
+    NttRange r;
+    PHA_TRY(make_range(ctx, count, start, 0, 0, 0, 0, r));
+    Epilogue ep{};
+    ep.cst = scale;
+    ep.cst_shoup = scale_shoup;
+    return ntt_backward(ctx, out, in, 1, 0, r, EPI_SCALE, ep, as_stream(stream));
+}
+
+int pha_nwt_2d_radix8_forward_inplace_include_special_mod(pha_context *ctx, uint64_t *inout, size_t count, size_t start,
+                                                          size_t size_QP, size_t size_P, pha_stream_t stream) {
+    REQUIRE_CTX(inout);
+    NttRange r;
+    PHA_TRY(make_range(ctx, count, start, size_QP, size_P, 0, 0, r));
+    return ntt_forward(ctx, inout, 1, 0, r, EPI_NONE, Epilogue{}, as_stream(stream));
+}
+
+int pha_nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range(pha_context *ctx, uint64_t *inout, size_t count,
+                                                                        size_t start, size_t size_QP, size_t size_P,
+                                                                        size_t excluded_range_start,
+                                                                        size_t excluded_range_end, pha_stream_t stream) {
+    REQUIRE_CTX(inout);
+    if (excluded_range_start < start || excluded_range_end > start + count)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "Excluded range in NTT is invalid.");
+    NttRange r;
+    PHA_TRY(make_range(ctx, count, start, size_QP, size_P, excluded_range_start, excluded_range_end, r));
+    return ntt_forward(ctx, inout, 1, 0, r, EPI_NONE, Epilogue{}, as_stream(stream));
+}
+
+int pha_nwt_2d_radix8_backward_inplace_include_special_mod(pha_context *ctx, uint64_t *inout, size_t count, size_t start,
+                                                           size_t size_QP, size_t size_P, pha_stream_t stream) {
+    REQUIRE_CTX(inout);
+    NttRange r;
+    PHA_TRY(make_range(ctx, count, start, size_QP, size_P, 0, 0, r));
+    return ntt_backward(ctx, inout, inout, 1, 0, r, EPI_NONE, Epilogue{}, as_stream(stream));
+}
+
+int pha_nwt_2d_radix8_forward_inplace_fuse_moddown(pha_context *ctx, uint64_t *ct, const uint64_t *cx,
+                                                   const uint64_t *bigPInv_mod_q, const uint64_t *bigPInv_mod_q_shoup,
+                                                   uint64_t *delta, size_t count, size_t start, pha_stream_t stream) {
+    REQUIRE_CTX(ct && cx && bigPInv_mod_q && bigPInv_mod_q_shoup && delta);
+    NttRange r;
+    PHA_TRY(make_range(ctx, count, start, 0, 0, 0, 0, r));
+    Epilogue ep{};
+    ep.out = ct;
+    ep.sub = cx;
+    ep.cst = bigPInv_mod_q;
+    ep.cst_shoup = bigPInv_mod_q_shoup;
+    return ntt_forward(ctx, delta, 1, 0, r, EPI_SUB_MUL, ep, as_stream(stream));
+}
+
+int pha_ntt_forward_batched(pha_context *ctx, uint64_t *inout, size_t polys, size_t poly_stride_limbs, size_t count,
+                            size_t start, pha_stream_t stream) {
+    REQUIRE_CTX(inout);
+    NttRange r;
+    PHA_TRY(make_range(ctx, count, start, 0, 0, 0, 0, r));
+    return ntt_forward(ctx, inout, polys, poly_stride_limbs * ctx->n, r, EPI_NONE, Epilogue{}, as_stream(stream));
+}
+
+int pha_ntt_backward_batched(pha_context *ctx, uint64_t *inout, size_t polys, size_t poly_stride_limbs, size_t count,
+                             size_t start, pha_stream_t stream) {
+    REQUIRE_CTX(inout);
+    NttRange r;
+    PHA_TRY(make_range(ctx, count, start, 0, 0, 0, 0, r));
+    return ntt_backward(ctx, inout, inout, polys, poly_stride_limbs * ctx->n, r, EPI_NONE, Epilogue{}, as_stream(stream));
+}
+
+int pha_modup(pha_context *ctx, size_t chain_index, uint64_t *dst, const uint64_t *cks, pha_stream_t stream) {
+    REQUIRE_CTX(dst && cks);
+    LevelTool *lt;
+    PHA_TRY(get_level(ctx, chain_index, &lt));
+    uint64_t *ws;
+    PHA_TRY(ensure_workspace(ctx, lt->size_Ql * ctx->n, &ws));
+    return do_modup(ctx, lt, dst, cks, ws, as_stream(stream));
+}
+
+int pha_key_switch_inner_prod(pha_context *ctx, size_t chain_index, uint64_t *p_cx, const uint64_t *p_t_mod_up,
+                              const uint64_t *const *evks, size_t reduction_threshold, pha_stream_t stream) {
+    (void)reduction_threshold;
+    REQUIRE_CTX(p_cx && p_t_mod_up && evks);
+    LevelTool *lt;
+    PHA_TRY(get_level(ctx, chain_index, &lt));
+    return do_inner_prod(ctx, lt, p_cx, p_t_mod_up, evks, as_stream(stream));
+}
+
+int pha_moddown_from_ntt(pha_context *ctx, size_t chain_index, uint64_t *ct_i, uint64_t *cx_i, pha_stream_t stream) {
+    REQUIRE_CTX(ct_i && cx_i);
+    LevelTool *lt;
+    PHA_TRY(get_level(ctx, chain_index, &lt));
+    uint64_t *ws;
+    PHA_TRY(ensure_workspace(ctx, lt->size_Ql * ctx->n, &ws));
+    return do_moddown(ctx, lt, ct_i, cx_i, ws, nullptr, as_stream(stream));
+}
+
+int pha_add_to_ct(pha_context *ctx, uint64_t *ct, const uint64_t *cx, size_t size_Ql, pha_stream_t stream) {
+    REQUIRE_CTX(ct && cx);
+    if (size_Ql == 0 || size_Ql > ctx->size_QP) return fail(PHA_ERR_INVALID_ARGUMENT, "limb range exceeds the modulus chain");
+    const uint32_t n = static_cast<uint32_t>(ctx->n);
+    hipLaunchKernelGGL(add_to_ct_kernel, dim3(static_cast<uint32_t>(size_Ql) * (n / 512)), dim3(256), 0, as_stream(stream),
+                       ct, cx, ctx->d_mod.p, n);
+    return check_launch("add_to_ct");
+}
+
+int pha_keyswitch_inplace(pha_context *ctx, size_t chain_index, uint64_t *ct, const uint64_t *c2,
+                          const uint64_t *const *evks, pha_stream_t stream) {
+    REQUIRE_CTX(ct && c2 && evks);
+    LevelTool *lt;
+    PHA_TRY(get_level(ctx, chain_index, &lt));
+    return do_keyswitch(ctx, lt, ct, c2, evks, as_stream(stream));
+}
+
+int pha_divide_and_round_q_last_ntt(pha_context *ctx, size_t chain_index, uint64_t *src, size_t cipher_size,
+                                    uint64_t *dst, pha_stream_t stream) {
+    REQUIRE_CTX(src && dst);
+    LevelTool *lt;
+    PHA_TRY(get_level(ctx, chain_index, &lt));
+    if (lt->size_Ql < 2) return fail(PHA_ERR_INVALID_ARGUMENT, "end of modulus switching chain reached");
+    const size_t n = ctx->n, size_Ql = lt->size_Ql;
+    NttRange r;
+    PHA_TRY(make_range(ctx, 1, size_Ql - 1, 0, 0, 0, 0, r));
+    PHA_TRY(ntt_backward(ctx, src, src, cipher_size, size_Ql * n, r, EPI_NONE, Epilogue{}, as_stream(stream)));
+    return do_rescale(ctx, lt, src, src + (size_Ql - 1) * n, size_Ql * n, cipher_size, dst, as_stream(stream));
+}
+
+int pha_apply_galois_ntt(pha_context *ctx, const uint64_t *operand, size_t coeff_mod_size, uint32_t galois_elt,
+                         uint64_t *result, pha_stream_t stream) {
+    REQUIRE_CTX(operand && result);
+    if (coeff_mod_size == 0) return fail(PHA_ERR_INVALID_ARGUMENT, "coeff_mod_size must be positive");
+    const uint32_t *perm;
+    PHA_TRY(get_galois_table(ctx, galois_elt, &perm));
+    hipStream_t st = as_stream(stream);
+    if (result == operand) {
+        uint64_t *ws;
+        PHA_TRY(ensure_workspace(ctx, coeff_mod_size * ctx->n, &ws));
+        PHA_TRY(do_galois(ctx, operand, coeff_mod_size, perm, ws, st));
+        HIP_TRY(hipMemcpyAsync(result, ws, coeff_mod_size * ctx->n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+        return PHA_OK;
+    }
+    return do_galois(ctx, operand, coeff_mod_size, perm, result, st);
+}
+
+int pha_tensor_prod_2x2(pha_context *ctx, const uint64_t *operand1, const uint64_t *operand2, size_t coeff_mod_size,
+                        uint64_t *result, pha_stream_t stream) {
+    REQUIRE_CTX(operand1 && operand2 && result);
+    if (coeff_mod_size == 0 || coeff_mod_size > ctx->size_QP)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "limb range exceeds the modulus chain");
+    const uint32_t n = static_cast<uint32_t>(ctx->n);
+    hipLaunchKernelGGL((tensor_prod_2x2_kernel<false>), dim3(static_cast<uint32_t>(coeff_mod_size) * (n / 512)), dim3(256),
+                       0, as_stream(stream), operand1, operand2, ctx->d_mod.p, result, n,
+                       static_cast<uint32_t>(coeff_mod_size));
+    return check_launch("tensor_prod_2x2");
+}
+
+int pha_tensor_square_2x2(pha_context *ctx, const uint64_t *operand, size_t coeff_mod_size, uint64_t *result,
+                          pha_stream_t stream) {
+    REQUIRE_CTX(operand && result);
+    if (coeff_mod_size == 0 || coeff_mod_size > ctx->size_QP)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "limb range exceeds the modulus chain");
+    const uint32_t n = static_cast<uint32_t>(ctx->n);
+    hipLaunchKernelGGL((tensor_prod_2x2_kernel<true>), dim3(static_cast<uint32_t>(coeff_mod_size) * (n / 512)), dim3(256),
+                       0, as_stream(stream), operand, operand, ctx->d_mod.p, result, n,
+                       static_cast<uint32_t>(coeff_mod_size));
+    return check_launch("tensor_square_2x2");
+}
+
+int pha_multiply_and_relin_inplace(pha_context *ctx, size_t chain_index, uint64_t *ct1, const uint64_t *ct2,
+                                   const uint64_t *const *relin_evks, pha_stream_t stream) {
+    REQUIRE_CTX(ct1 && ct2 && relin_evks);
+    LevelTool *lt;
+    PHA_TRY(get_level(ctx, chain_index, &lt));
+    const size_t size_Ql = lt->size_Ql;
+    if (ct1 == ct2)
+        PHA_TRY(pha_tensor_square_2x2(ctx, ct1, size_Ql, ct1, stream));
+    else
+        PHA_TRY(pha_tensor_prod_2x2(ctx, ct1, ct2, size_Ql, ct1, stream));
+    return do_keyswitch(ctx, lt, ct1, ct1 + 2 * size_Ql * ctx->n, relin_evks, as_stream(stream));
+}
+
+int pha_apply_galois_inplace(pha_context *ctx, size_t chain_index, uint64_t *ct, uint32_t galois_elt,
+                             const uint64_t *const *galois_evks, pha_stream_t stream) {
+    REQUIRE_CTX(ct && galois_evks);
+    LevelTool *lt;
+    PHA_TRY(get_level(ctx, chain_index, &lt));
+    const uint32_t *perm;
+    PHA_TRY(get_galois_table(ctx, galois_elt, &perm));
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, size_QlP = size_Ql + ctx->size_P;
+    hipStream_t st = as_stream(stream);
+    // workspace: [key-switch scratch][temp for both permuted polys]
+    const size_t ks_words = (lt->beta * size_QlP + 2 * size_QlP + size_Ql) * n;
+    uint64_t *ws;
+    PHA_TRY(ensure_workspace(ctx, ks_words + 2 * size_Ql * n, &ws));
+    uint64_t *temp = ws + ks_words;
+    // c0 <- galois(c0); temp1 <- galois(c1); c1 <- 0; ct += KS(temp1)   (src/evaluate.cu:774-793)
+    PHA_TRY(do_galois(ctx, ct, 2 * size_Ql, perm, temp, st));
+    HIP_TRY(hipMemcpyAsync(ct, temp, size_Ql * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemsetAsync(ct + size_Ql * n, 0, size_Ql * n * sizeof(uint64_t), st));
+    return do_keyswitch(ctx, lt, ct, temp + size_Ql * n, galois_evks, st);
+}
+
+int pha_rescale_to_next(pha_context *ctx, size_t chain_index, const uint64_t *src, size_t cipher_size, uint64_t *dst,
+                        pha_stream_t stream) {
+    REQUIRE_CTX(src && dst);
+    LevelTool *lt;
+    PHA_TRY(get_level(ctx, chain_index, &lt));
+    if (lt->size_Ql < 2) return fail(PHA_ERR_INVALID_ARGUMENT, "end of modulus switching chain reached");
+    const size_t n = ctx->n, size_Ql = lt->size_Ql;
+    hipStream_t st = as_stream(stream);
+    uint64_t *ws;
+    PHA_TRY(ensure_workspace(ctx, cipher_size * n, &ws));
+    // INTT of each poly's last limb, out of place into the workspace: view the workspace as a
+    // buffer whose limb (size_Ql-1) of poly p sits at ws + p*n
+    NttRange r;
+    PHA_TRY(make_range(ctx, 1, size_Ql - 1, 0, 0, 0, 0, r));
+    for (size_t p = 0; p < cipher_size; p++) {
+        PHA_TRY(ntt_backward(ctx, ws + p * n - (size_Ql - 1) * n, src + p * size_Ql * n, 1, 0, r, EPI_NONE, Epilogue{}, st));
+    }
+    return do_rescale(ctx, lt, src, ws, n, cipher_size, dst, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,195 @@
+// Base conversion, key-switch inner product, Galois gather, tensor product and element-wise
+// kernels for gfx950.  Arithmetic restates src/rns_bconv.cu, src/eval_key_switch.cu,
+// src/galois.cu, src/polymath.cu and src/rns.cu:1125-1155 of the reference; every stored value
+// is the canonical residue, so results are bit-identical.
+#pragma once
+
+#include "modarith.cuh"
+
+namespace pha {
+
+// ---------------------------------------------------------------------------------------------
+// fast base conversion, phase 2 (src/rns_bconv.cu:143-168,455-485, include/rns_bconv.cuh:127-143):
+//   dst[jo][k] = sum_i y[i][k] * M[j][i] mod p_j,  jo = j + (j >= skip_start ? skip_len : 0)
+// One lane owns one coefficient: its IB inputs stay in registers and are reused for every
+// output limb of the block's limb group; the matrix row is wave-uniform (scalar loads).
+// ---------------------------------------------------------------------------------------------
+template <int IB>
+__global__ __launch_bounds__(256) void bconv_matmul_kernel(uint64_t *dst, const uint64_t *y, const uint64_t *matrix,
+                                                           const DModulus *obase_mod, const uint32_t *obase_tidx,
+                                                           uint32_t obase_size, uint32_t limbs_per_block, uint32_t n,
+                                                           uint32_t skip_start, uint32_t skip_len) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    uint64_t in[IB];
+#pragma unroll
+    for (int i = 0; i < IB; i++) in[i] = y[static_cast<size_t>(i) * n + k];
+    const uint32_t j0 = blockIdx.y * limbs_per_block;
+    const uint32_t j1 = min(j0 + limbs_per_block, obase_size);
+    for (uint32_t j = j0; j < j1; j++) {
+        const uint64_t *row = matrix + static_cast<size_t>(j) * IB;
+        u128_t acc = mul64x64(in[0], row[0]);
+#pragma unroll
+        for (int i = 1; i < IB; i++) add128(acc, mul64x64(in[i], row[i]));
+        const DModulus m = obase_mod[obase_tidx[j]];
+        const uint32_t jo = j + (j >= skip_start ? skip_len : 0);
+        dst[static_cast<size_t>(jo) * n + k] = barrett128(acc, m);
+    }
+}
+
+// generic fallback for ibase sizes without an instantiation
+__global__ __launch_bounds__(256) void bconv_matmul_generic_kernel(uint64_t *dst, const uint64_t *y,
+                                                                   const uint64_t *matrix, const DModulus *obase_mod,
+                                                                   const uint32_t *obase_tidx, uint32_t ibase_size,
+                                                                   uint32_t obase_size, uint32_t limbs_per_block,
+                                                                   uint32_t n, uint32_t skip_start, uint32_t skip_len) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t j0 = blockIdx.y * limbs_per_block;
+    const uint32_t j1 = min(j0 + limbs_per_block, obase_size);
+    for (uint32_t j = j0; j < j1; j++) {
+        const uint64_t *row = matrix + static_cast<size_t>(j) * ibase_size;
+        u128_t acc = {0, 0};
+        for (uint32_t i = 0; i < ibase_size; i++) add128(acc, mul64x64(y[static_cast<size_t>(i) * n + k], row[i]));
+        const DModulus m = obase_mod[obase_tidx[j]];
+        const uint32_t jo = j + (j >= skip_start ? skip_len : 0);
+        dst[static_cast<size_t>(jo) * n + k] = barrett128(acc, m);
+    }
+}
+
+// alpha == 1 modup (src/rns_bconv.cu:432-453): every digit is one limb; dst[d][j][k] is the raw
+// NTT-form limb for j == d and (coeff mod p_j) otherwise.
+__global__ __launch_bounds__(256) void modup_single_p_kernel(uint64_t *dst, const uint64_t *cks_ntt,
+                                                             const uint64_t *cks_coeff, const DModulus *mod,
+                                                             uint32_t size_Ql, uint32_t size_Q, uint32_t n) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t d = blockIdx.y;
+    const uint32_t size_QlP = size_Ql + 1;
+    const uint64_t coeff = cks_coeff[static_cast<size_t>(d) * n + k];
+    const uint64_t in_prime = mod[d].value;
+    uint64_t *o = dst + static_cast<size_t>(d) * size_QlP * n + k;
+    for (uint32_t j = 0; j < size_QlP; j++) {
+        uint64_t v;
+        if (j == d) {
+            v = cks_ntt[static_cast<size_t>(d) * n + k];
+        } else {
+            const DModulus m = mod[j < size_Ql ? j : size_Q];
+            v = in_prime > m.value ? barrett64(coeff, m.value, m.ratio1) : coeff;
+        }
+        o[static_cast<size_t>(j) * n] = v;
+    }
+}
+
+// dst[j][k] = src[k] mod q_j for j < limbs (src/rns_bconv.cu:691-707, src/rns.cu:1125-1136)
+__global__ __launch_bounds__(256) void reduce_single_limb_kernel(uint64_t *dst, const uint64_t *src,
+                                                                 const DModulus *mod, uint32_t limbs, uint32_t n,
+                                                                 size_t dst_poly_stride, size_t src_poly_stride) {
+    const uint32_t k = (blockIdx.x * 256 + threadIdx.x) * 2;
+    const ulonglong2 c = *reinterpret_cast<const ulonglong2 *>(src + blockIdx.y * src_poly_stride + k);
+    uint64_t *o = dst + blockIdx.y * dst_poly_stride + k;
+    for (uint32_t j = 0; j < limbs; j++) {
+        const DModulus m = mod[j];
+        ulonglong2 v;
+        v.x = barrett64(c.x, m.value, m.ratio1);
+        v.y = barrett64(c.y, m.value, m.ratio1);
+        *reinterpret_cast<ulonglong2 *>(o + static_cast<size_t>(j) * n) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// key-switch inner product (src/eval_key_switch.cu:12-66): two 128-bit dot products over the
+// beta digits per coefficient, one Barrett each.  Pure streaming: 16 B per lane per access.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void key_switch_inner_prod_kernel(uint64_t *dst, const uint64_t *t_mod_up,
+                                                                    const uint64_t *const *evks, const DModulus *mod,
+                                                                    uint32_t n, uint32_t size_QP, uint32_t size_QlP,
+                                                                    uint32_t size_Q, uint32_t size_Ql, uint32_t beta) {
+    const uint32_t per_limb = n / 512;
+    const uint32_t nid = blockIdx.x / per_limb;
+    const uint32_t k = ((blockIdx.x % per_limb) * 256 + threadIdx.x) * 2;
+    const uint32_t twr = nid >= size_Ql ? size_Q + (nid - size_Ql) : nid;
+    const DModulus m = mod[twr];
+    const size_t c2_id = static_cast<size_t>(nid) * n + k;
+    const size_t evk_id = static_cast<size_t>(twr) * n + k;
+    const size_t size_QlP_n = static_cast<size_t>(size_QlP) * n, size_QP_n = static_cast<size_t>(size_QP) * n;
+    u128_t a0x = {0, 0}, a0y = {0, 0}, a1x = {0, 0}, a1y = {0, 0};
+    for (uint32_t d = 0; d < beta; d++) {
+        const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(t_mod_up + d * size_QlP_n + c2_id);
+        const uint64_t *evk = evks[d];
+        const ulonglong2 e0 = *reinterpret_cast<const ulonglong2 *>(evk + evk_id);
+        const ulonglong2 e1 = *reinterpret_cast<const ulonglong2 *>(evk + size_QP_n + evk_id);
+        add128(a0x, mul64x64(t.x, e0.x));
+        add128(a0y, mul64x64(t.y, e0.y));
+        add128(a1x, mul64x64(t.x, e1.x));
+        add128(a1y, mul64x64(t.y, e1.y));
+    }
+    ulonglong2 r0, r1;
+    r0.x = barrett128(a0x, m);
+    r0.y = barrett128(a0y, m);
+    r1.x = barrett128(a1x, m);
+    r1.y = barrett128(a1y, m);
+    *reinterpret_cast<ulonglong2 *>(dst + c2_id) = r0;
+    *reinterpret_cast<ulonglong2 *>(dst + size_QlP_n + c2_id) = r1;
+}
+
+// ct[l][k] = ct[l][k] + cx[l][k] mod q_l (src/rns_bconv.cu:763-769)
+__global__ __launch_bounds__(256) void add_to_ct_kernel(uint64_t *ct, const uint64_t *cx, const DModulus *mod,
+                                                        uint32_t n) {
+    const uint32_t per_limb = n / 512;
+    const uint32_t l = blockIdx.x / per_limb;
+    const size_t id = static_cast<size_t>(l) * n + ((blockIdx.x % per_limb) * 256 + threadIdx.x) * 2;
+    const uint64_t q = mod[l].value;
+    ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(ct + id);
+    const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(cx + id);
+    a.x = csub(a.x + b.x, q);
+    a.y = csub(a.y + b.y, q);
+    *reinterpret_cast<ulonglong2 *>(ct + id) = a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Galois automorphism in the NTT domain = index gather (src/galois.cu:8-18)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void apply_galois_ntt_kernel(uint64_t *dst, const uint64_t *src,
+                                                               const uint32_t *perm, uint32_t n) {
+    const uint32_t per_limb = n / 512;
+    const uint32_t l = blockIdx.x / per_limb;
+    const uint32_t i = ((blockIdx.x % per_limb) * 256 + threadIdx.x) * 2;
+    const uint2 p = *reinterpret_cast<const uint2 *>(perm + i);
+    const uint64_t *s = src + static_cast<size_t>(l) * n;
+    ulonglong2 v;
+    v.x = s[p.x];
+    v.y = s[p.y];
+    *reinterpret_cast<ulonglong2 *>(dst + static_cast<size_t>(l) * n + i) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dyadic ciphertext product (src/polymath.cu:468-537): d0 = a0 b0, d1 = a0 b1 + a1 b0, d2 = a1 b1
+// ---------------------------------------------------------------------------------------------
+template <bool SQUARE>
+__global__ __launch_bounds__(256) void tensor_prod_2x2_kernel(const uint64_t *op1, const uint64_t *op2,
+                                                              const DModulus *mod, uint64_t *res, uint32_t n,
+                                                              uint32_t limbs) {
+    const uint32_t per_limb = n / 512;
+    const uint32_t l = blockIdx.x / per_limb;
+    const size_t id = static_cast<size_t>(l) * n + ((blockIdx.x % per_limb) * 256 + threadIdx.x) * 2;
+    const size_t rc = static_cast<size_t>(limbs) * n;
+    const DModulus m = mod[l];
+    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(op1 + id);
+    const ulonglong2 a1 = *reinterpret_cast<const ulonglong2 *>(op1 + id + rc);
+    const ulonglong2 b0 = SQUARE ? a0 : *reinterpret_cast<const ulonglong2 *>(op2 + id);
+    const ulonglong2 b1 = SQUARE ? a1 : *reinterpret_cast<const ulonglong2 *>(op2 + id + rc);
+    ulonglong2 d0, d1, d2;
+    d0.x = mul_barrett(a0.x, b0.x, m);
+    d0.y = mul_barrett(a0.y, b0.y, m);
+    d2.x = mul_barrett(a1.x, b1.x, m);
+    d2.y = mul_barrett(a1.y, b1.y, m);
+    // Karatsuba form of the reference: (a0+a1)(b0+b1) - d0 - d2; operands < 2q, product < 2^124
+    const uint64_t q = m.value;
+    uint64_t tx = mul_barrett(a0.x + a1.x, b0.x + b1.x, m) + 2 * q - d0.x - d2.x;
+    uint64_t ty = mul_barrett(a0.y + a1.y, b0.y + b1.y, m) + 2 * q - d0.y - d2.y;
+    d1.x = csub(csub(tx, q), q);
+    d1.y = csub(csub(ty, q), q);
+    *reinterpret_cast<ulonglong2 *>(res + id) = d0;
+    *reinterpret_cast<ulonglong2 *>(res + id + rc) = d1;
+    *reinterpret_cast<ulonglong2 *>(res + id + 2 * rc) = d2;
+}
+
+}  // namespace pha

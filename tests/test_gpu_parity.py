@@ -1,0 +1,232 @@
+"""GPU parity: every C-ABI compute entry point against the CPU oracle on the same seeded inputs
+(bit-exact — integer work), through the C ABI (ctypes), on a real MI355X."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(pha, a):
+    return pha.to_device(a)
+
+
+def _host(pha, t):
+    return pha.to_host(t)
+
+
+@pytest.fixture(scope="module")
+def small(gpu, pha, orc):
+    """N = 4096, Q = 6 x 45-bit, P = 2 x 55-bit: alpha = 2, beta = 3."""
+    mods = orc.coeff_modulus_create(4096, [45] * 6 + [55] * 2)
+    return pha.PhantomContext(12, mods, 2), orc.Oracle(12, mods, 2)
+
+
+@pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16])
+def test_ntt_forward_backward_all_sizes(gpu, pha, orc, log_n):
+    n = 1 << log_n
+    mods = orc.coeff_modulus_create(n, [60, 50, 40, 60])
+    ctx, o = pha.PhantomContext(log_n, mods, 1), orc.Oracle(log_n, mods, 1)
+    for which in range(4):
+        assert (ctx.get_table(2, which) == o.table(which, 2)).all()
+    x = o.uniform_poly([0, 1, 2, 3], 100 + log_n)
+    ref = x.copy()
+    o.nwt_forward_inplace(ref, 4, 0)
+    d = _dev(pha, x)
+    ctx.nwt_2d_radix8_forward_inplace(d, 4, 0)
+    assert (_host(pha, d) == ref).all()
+    ctx.nwt_2d_radix8_backward_inplace(d, 4, 0)
+    assert (_host(pha, d) == x).all()
+    # sub-range with a start index: limbs 1..2 only
+    d = _dev(pha, x)
+    ctx.nwt_2d_radix8_forward_inplace(d, 2, 1)
+    got = _host(pha, d)
+    assert (got[1:3] == ref[1:3]).all() and (got[0] == x[0]).all() and (got[3] == x[3]).all()
+    ctx.close()
+
+
+def test_forward_tolerates_lazy_inputs(gpu, pha, small):
+    ctx, o = small
+    x = o.uniform_poly([0], 1)
+    ref = x.copy()
+    o.nwt_forward_inplace(ref, 1, 0)
+    d = _dev(pha, x + np.uint64(3 * int(o.moduli[0])))
+    ctx.nwt_2d_radix8_forward_inplace(d, 1, 0)
+    assert (_host(pha, d) == ref).all()
+
+
+def test_backward_out_of_place_and_scale(gpu, pha, small):
+    ctx, o = small
+    x = o.uniform_poly(list(range(6)), 2)
+    ref = np.zeros_like(x)
+    o.nwt_backward(ref, x, 6, 0)
+    din, dout = _dev(pha, x), _dev(pha, np.zeros_like(x))
+    ctx.nwt_2d_radix8_backward(dout, din, 6, 0)
+    assert (_host(pha, dout) == ref).all() and (_host(pha, din) == x).all()
+    scale = np.array([int(m) // 3 + 17 for m in o.moduli[:6]], dtype=np.uint64)
+    shoup = np.array([(int(s) << 64) // int(m) for s, m in zip(scale, o.moduli[:6])], dtype=np.uint64)
+    o.nwt_backward_scale(ref, x, 6, 0, scale)
+    ctx.nwt_2d_radix8_backward_scale(dout, din, 6, 0, _dev(pha, scale), _dev(pha, shoup))
+    assert (_host(pha, dout) == ref).all()
+
+
+def test_special_mod_variants(gpu, pha, small):
+    ctx, o = small
+    size_ql = 4
+    tidx = list(range(size_ql)) + [6, 7]
+    x = o.uniform_poly(tidx, 3)
+    ref = x.copy()
+    o.nwt_forward_inplace_special(ref, 6, 0, 8, 2)
+    d = _dev(pha, x)
+    ctx.nwt_2d_radix8_forward_inplace_include_special_mod(d, 6, 0, 8, 2)
+    assert (_host(pha, d) == ref).all()
+    ref2 = x.copy()
+    o.nwt_forward_inplace_special(ref2, 6, 0, 8, 2, 2, 4)
+    d = _dev(pha, x)
+    ctx.nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range(d, 6, 0, 8, 2, 2, 4)
+    assert (_host(pha, d) == ref2).all()
+    ref3 = x.copy()
+    o.nwt_backward_inplace_special(ref3, 2, size_ql, 8, 2)
+    d = _dev(pha, x)
+    ctx.nwt_2d_radix8_backward_inplace_include_special_mod(d, 2, size_ql, 8, 2)
+    assert (_host(pha, d) == ref3).all()
+    with pytest.raises(pha.PhantomError) as e:
+        ctx.nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range(d, 4, 1, 8, 2, 0, 2)
+    assert e.value.code == pha.PHA_ERR_INVALID_ARGUMENT
+    with pytest.raises(pha.PhantomError):
+        ctx.nwt_2d_radix8_forward_inplace(d, 9, 0)
+
+
+def test_fuse_moddown(gpu, pha, small):
+    ctx, o = small
+    size_ql = 5
+    lc = o.level_constants(size_ql)
+    pinv = lc["bigPInv_mod_q"]
+    shoup = np.array([(int(s) << 64) // int(m) for s, m in zip(pinv, o.moduli[:size_ql])], dtype=np.uint64)
+    delta, cx = o.uniform_poly(list(range(size_ql)), 4), o.uniform_poly(list(range(size_ql)), 5)
+    ref = np.zeros_like(cx)
+    o.nwt_forward_fuse_moddown(ref, cx, pinv, delta.copy(), size_ql, 0)
+    dct = _dev(pha, np.zeros_like(cx))
+    ctx.nwt_2d_radix8_forward_inplace_fuse_moddown(dct, _dev(pha, cx), _dev(pha, pinv), _dev(pha, shoup),
+                                                   _dev(pha, delta), size_ql, 0)
+    assert (_host(pha, dct) == ref).all()
+
+
+def _uniform_evk(pha, o, seed):
+    dnum = o.size_Q // o.size_P
+    host = [np.ascontiguousarray(np.stack([o.uniform_poly(list(range(o.size_QP)), seed + 10 * d),
+                                            o.uniform_poly(list(range(o.size_QP)), seed + 10 * d + 1)]))
+            for d in range(dnum)]
+    return host, pha.EvalKey([pha.to_device(h) for h in host])
+
+
+@pytest.mark.parametrize("size_p,chain_index", [(2, 1), (2, 2), (2, 4), (1, 1), (1, 3), (3, 1), (3, 3)])
+def test_keyswitch_pipeline(gpu, pha, orc, size_p, chain_index):
+    """modup, inner product, moddown and the whole keyswitch_inplace, alpha = 1 and alpha > 1,
+    full and ragged last digit.  A uniform evk is enough for arithmetic parity."""
+    mods = orc.coeff_modulus_create(4096, [45] * 6 + [55] * size_p)
+    ctx, o = pha.PhantomContext(12, mods, size_p), orc.Oracle(12, mods, size_p)
+    size_ql = ctx.size_Ql(chain_index)
+    size_qlp = size_ql + size_p
+    evk_h, evk_d = _uniform_evk(pha, o, 70)
+    c2 = o.uniform_poly(list(range(size_ql)), 6)
+    t_ref = o.modup(size_ql, c2)
+    d_t = _dev(pha, np.zeros_like(t_ref))
+    ctx.modup(chain_index, d_t, _dev(pha, c2))
+    assert (_host(pha, d_t) == t_ref).all()
+    cx_ref = o.key_switch_inner_prod(size_ql, t_ref, evk_h)
+    d_cx = _dev(pha, np.zeros_like(cx_ref))
+    ctx.key_switch_inner_prod(chain_index, d_cx, d_t, evk_d)
+    assert (_host(pha, d_cx) == cx_ref).all()
+    for i in range(2):
+        md_ref = o.moddown_from_ntt(size_ql, cx_ref[i])
+        d_ct = _dev(pha, np.zeros((size_ql, 4096), dtype=np.uint64))
+        ctx.moddown_from_NTT(chain_index, d_ct, d_cx[i])
+        assert (_host(pha, d_ct) == md_ref).all()
+    ct = np.stack([o.uniform_poly(list(range(size_ql)), 7), o.uniform_poly(list(range(size_ql)), 8)])
+    ct_ref = ct.copy()
+    o.keyswitch_inplace(size_ql, ct_ref, c2, evk_h)
+    d_ct = _dev(pha, ct)
+    ctx.keyswitch_inplace(chain_index, d_ct, _dev(pha, c2), evk_d)
+    assert (_host(pha, d_ct) == ct_ref).all()
+    # add_to_ct on its own
+    a, b = ct[0], ct[1]
+    d_a = _dev(pha, a)
+    ctx.add_to_ct(d_a, _dev(pha, b), size_ql)
+    exp = np.stack([((a[i].astype(object) + b[i].astype(object)) % int(mods[i])) for i in range(size_ql)])
+    assert (_host(pha, d_a).astype(object) == exp).all()
+    assert size_qlp == t_ref.shape[1]
+    ctx.close()
+
+
+def test_galois_and_rotate(gpu, pha, orc, small):
+    ctx, o = small
+    size_ql = 6
+    x = o.uniform_poly(list(range(size_ql)), 9)
+    for step in (1, -3, 0):
+        elt = pha.galois_elt_from_step(12, step)
+        ref = o.apply_galois_ntt(x, elt)
+        d_out = _dev(pha, np.zeros_like(x))
+        ctx.apply_galois_ntt(_dev(pha, x), size_ql, elt, d_out)
+        assert (_host(pha, d_out) == ref).all()
+        d_in = _dev(pha, x)
+        ctx.apply_galois_ntt(d_in, size_ql, elt, d_in)  # in place
+        assert (_host(pha, d_in) == ref).all()
+    # apply_galois_inplace = permute both polys, key-switch the permuted c1 (src/evaluate.cu:747-794)
+    evk_h, evk_d = _uniform_evk(pha, o, 80)
+    ct = np.stack([o.uniform_poly(list(range(size_ql)), 10), o.uniform_poly(list(range(size_ql)), 11)])
+    elt = 5
+    ref = np.stack([o.apply_galois_ntt(ct[0], elt), np.zeros_like(ct[1])])
+    o.keyswitch_inplace(size_ql, ref, o.apply_galois_ntt(ct[1], elt), evk_h)
+    d_ct = _dev(pha, ct)
+    ctx.apply_galois_inplace(1, d_ct, elt, evk_d)
+    assert (_host(pha, d_ct) == ref).all()
+    with pytest.raises(pha.PhantomError):
+        ctx.apply_galois_ntt(d_ct, size_ql, 6, d_ct)
+
+
+@pytest.mark.parametrize("chain_index", [1, 3])
+def test_rescale(gpu, pha, small, chain_index):
+    ctx, o = small
+    size_ql = ctx.size_Ql(chain_index)
+    src = np.stack([o.uniform_poly(list(range(size_ql)), 12), o.uniform_poly(list(range(size_ql)), 13)])
+    ref = o.divide_and_round_q_last_ntt(size_ql, src, 2)
+    d_src, d_dst = _dev(pha, src), _dev(pha, np.zeros_like(ref))
+    ctx.rescale_to_next(chain_index, d_src, 2, d_dst)
+    assert (_host(pha, d_dst) == ref).all()
+    assert (_host(pha, d_src) == src).all()  # rescale_to_next preserves its input
+    d_dst2 = _dev(pha, np.zeros_like(ref))
+    ctx.divide_and_round_q_last_ntt(chain_index, d_src, 2, d_dst2)  # reference semantics: src destroyed
+    assert (_host(pha, d_dst2) == ref).all()
+
+
+def test_tensor_and_multiply_relin(gpu, pha, small):
+    ctx, o = small
+    size_ql = 6
+    a = np.stack([o.uniform_poly(list(range(size_ql)), 14), o.uniform_poly(list(range(size_ql)), 15)])
+    b = np.stack([o.uniform_poly(list(range(size_ql)), 16), o.uniform_poly(list(range(size_ql)), 17)])
+    ref = o.tensor_prod_2x2(a, b)
+    d_res = _dev(pha, np.zeros_like(ref))
+    ctx.tensor_prod_2x2(_dev(pha, a), _dev(pha, b), size_ql, d_res)
+    assert (_host(pha, d_res) == ref).all()
+    ctx.tensor_square_2x2(_dev(pha, a), size_ql, d_res)
+    assert (_host(pha, d_res) == o.tensor_prod_2x2(a, a)).all()
+    # multiply_inplace + relinearize_inplace (src/evaluate.cu:229-280,553-583)
+    evk_h, evk_d = _uniform_evk(pha, o, 90)
+    exp = ref[:2].copy()
+    o.keyswitch_inplace(size_ql, exp, ref[2], evk_h)
+    d_ct1 = _dev(pha, np.concatenate([a, np.zeros_like(a[:1])]))
+    ctx.multiply_and_relin_inplace(1, d_ct1, _dev(pha, b), evk_d)
+    assert (_host(pha, d_ct1)[:2] == exp).all()
+
+
+def test_bad_chain_index(gpu, pha, small):
+    ctx, o = small
+    import torch
+    d = torch.zeros(8 * 4096, dtype=torch.int64, device="cuda")
+    with pytest.raises(pha.PhantomError) as e:
+        ctx.modup(0, d, d)
+    assert e.value.code == pha.PHA_ERR_INVALID_ARGUMENT
+    with pytest.raises(pha.PhantomError):
+        ctx.modup(7, d, d)
+    with pytest.raises(pha.PhantomError):
+        ctx.rescale_to_next(6, d, 2, d)  # one limb left: end of chain
