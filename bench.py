@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json metric on its configs[1]: batched RNS NTT/INTT, N = 2^16,
+36 limbs x 2 polys (uint64[2][36][65536]), one MI355X per rank.
+
+A step = one forward NTT of the whole batch followed by one inverse NTT of it (the round trip
+keeps the buffer canonical), i.e. 144 limb-transforms through the C ABI
+(pha_ntt_forward_batched / pha_ntt_backward_batched).  Inputs are resident in HBM before the
+timed region.  value = limb-transforms per second over all ranks (weak scaling: every rank owns
+its own batch, the path has no exchange step, so no collective on the data path).
+
+Extra objects on the JSON line:
+  roofline     — the dominant kernel (the forward row-phase kernel), timed live with HIP events
+                 on the launching stream; algorithmic bytes = N*8 read + N*8 write per limb per
+                 launch.  `transform_frac` is the same figure for the whole
+                 forward transform (both kernels of a limb-NTT share the 1 MiB of algorithmic
+                 bytes) — the number the >=60 % target is about.
+  cpu_baseline — the oracle (a scalar port; kind "port") timed on the host cores on a bounded
+                 sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+LOG_N = 16
+N = 1 << LOG_N
+LIMBS = 36
+POLYS = 2
+BITS = [60] + [50] * 35  # BASELINE.md config 2 / SURVEY.md §8(d): first prime 60-bit, scale primes 50-bit
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ALGO_BYTES_PER_LIMB = N * 8 * 2
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc-traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
+                    help="per-launch HBM bytes of the dominant kernel from a separate rocprofv3 --pmc pass")
+    return ap.parse_args()
+
+
+def event_time_ms(torch, fn, reps):
+    """Average duration of fn() over reps back-to-back launches, HIP events on the current stream."""
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(reps):
+        fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) / reps
+
+
+def event_time_each_ms(torch, fn, reps):
+    """Median of per-launch event pairs."""
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in pairs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in pairs)
+    return ts[len(ts) // 2]
+
+
+def cpu_baseline(mods, budget_s=12.0):
+    """Oracle forward+inverse over the same batch shape on the host cores (bounded sample)."""
+    import numpy as np
+
+    import oracle
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    threads = min(threads, os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    oracle.build()
+    orc = oracle.Oracle(LOG_N, mods, 0)
+    buf = np.ascontiguousarray(orc.uniform_poly(list(range(LIMBS)), 2))
+    orc.nwt_forward_inplace(buf, LIMBS, 0)  # warm-up
+    orc.nwt_backward_inplace(buf, LIMBS, 0)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        orc.nwt_forward_inplace(buf, LIMBS, 0)
+        orc.nwt_backward_inplace(buf, LIMBS, 0)
+        done += 2 * LIMBS
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            break
+    return {"value": done / el, "unit": "limb-transforms/s", "cores": threads, "kind": "port",
+            "sample": f"{done} limb-transforms (36-limb poly, N=2^16, forward+inverse passes) in {el:.1f} s, "
+                      f"OpenMP over limbs"}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+
+    import phantom_fhe_amd as pha
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+
+    mods = pha.coeff_modulus_create(N, BITS)
+    ctx = pha.PhantomContext(LOG_N, mods, 0)
+    # synthetic input: uniform residues, seeded per rank (data: synthetic)
+    rng = np.random.default_rng(2 + rank)
+    host = np.stack([np.stack([rng.integers(0, int(q), size=N, dtype=np.uint64) for q in mods]) for _ in range(POLYS)])
+    buf = pha.to_device(host)
+    orig = buf.clone()
+
+    def step():
+        ctx.ntt_forward_batched(buf, POLYS, LIMBS, LIMBS, 0)
+        ctx.ntt_backward_batched(buf, POLYS, LIMBS, LIMBS, 0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # size-independent property at full size: the round trips returned the input bit-for-bit
+    assert torch.equal(buf, orig), "INTT(NTT(x)) != x after the timed region"
+
+    units_per_step = 2 * POLYS * LIMBS
+    value = world * units_per_step * args.steps / elapsed
+    out = {
+        "metric": "RNS-NTT limb-transforms/s @N=2^16 (forward+inverse, 36 limbs x 2 polys per GPU)",
+        "value": value, "unit": "limb-transforms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "configs[1]: batched RNS NTT+INTT, N=2^16, 36 limbs x 2 polys, uint64[2][36][65536] per GPU",
+                   "limbs": LIMBS, "polys": POLYS, "log_n": LOG_N, "parallelism": f"independent batches x{world}"},
+    }
+
+    if rank == 0:
+        # dominant kernel, live: forward row-phase kernel over the whole batch, one launch = 72 limbs
+        reps = max(50, args.steps)
+        phase = {}
+        for name, inv, ph in (("fwd_col", 0, 0), ("fwd_row", 0, 1), ("inv_row", 1, 1), ("inv_col", 1, 0)):
+            fn = (lambda inv=inv, ph=ph: ctx.ntt_launch_phase(buf, POLYS, LIMBS, LIMBS, 0, inv, ph))
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            phase[name] = {"avg_ms_back_to_back": event_time_ms(torch, fn, reps),
+                           "median_ms_per_launch_events": event_time_each_ms(torch, fn, reps)}
+        buf.copy_(orig)
+        fwd_ms = event_time_ms(torch, lambda: ctx.ntt_forward_batched(buf, POLYS, LIMBS, LIMBS, 0), reps)
+        buf.copy_(orig)
+        dom = max(("fwd_col", "fwd_row"), key=lambda k: phase[k]["avg_ms_back_to_back"])
+        dom_ms = phase[dom]["avg_ms_back_to_back"]
+        algo = POLYS * LIMBS * ALGO_BYTES_PER_LIMB
+        achieved = algo / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        try:
+            with open(args.pmc_traffic_json) as f:
+                traffic = json.load(f).get(dom)
+        except Exception:
+            traffic = None
+        out["roofline"] = {
+            "bound": "hbm", "kernel": {"fwd_row": "fntt_row_kernel<8,4,0>", "fwd_col": "fntt_col_kernel<8,4>"}[dom],
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": dom_ms,
+            "transform_frac": algo / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "forward_transform_ms": fwd_ms,
+            "phases": phase,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(mods)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -113,6 +113,14 @@ int pha_ntt_forward_batched(pha_context *ctx, uint64_t *inout, size_t polys, siz
 int pha_ntt_backward_batched(pha_context *ctx, uint64_t *inout, size_t polys, size_t poly_stride_limbs,
                              size_t coeff_modulus_size, size_t start_modulus_idx, pha_stream_t stream);
 
+/* Measurement aid (no reference counterpart): launch only ONE of the two kernels of a
+ * transform (phase 0 = column kernel, 1 = row kernel; inverse != 0 selects the INTT pair) so that
+ * bench.py can time the dominant kernel with HIP events.  The buffer contents afterwards are an
+ * unfinished transform. */
+int pha_ntt_launch_phase(pha_context *ctx, uint64_t *inout, size_t polys, size_t poly_stride_limbs,
+                         size_t coeff_modulus_size, size_t start_modulus_idx, int inverse, int phase,
+                         pha_stream_t stream);
+
 /* ---- DRNSTool (include/rns.cuh:155-185); chain_index as in the reference:
  *      1 = first data level (all of Q), k = Q minus its last k-1 primes (src/context.cu:148-174) */
 /* DRNSTool::modup, CKKS branch (src/rns_bconv.cu:530-628): dst[beta][size_QlP][N] */

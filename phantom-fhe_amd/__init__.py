@@ -61,6 +61,7 @@ SIGNATURES = {
     "pha_nwt_2d_radix8_forward_inplace_fuse_moddown": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "pha_ntt_forward_batched": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "pha_ntt_backward_batched": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "pha_ntt_launch_phase": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _int, _int, _vp]),
     "pha_modup": (_int, [_vp, _sz, _vp, _vp, _vp]),
     "pha_key_switch_inner_prod": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _vp]),
     "pha_moddown_from_ntt": (_int, [_vp, _sz, _vp, _vp, _vp]),
@@ -272,6 +273,10 @@ class PhantomContext:
 
     def ntt_backward_batched(self, inout, polys, poly_stride_limbs, count, start=0):
         _check(lib().pha_ntt_backward_batched(self._h, _ptr(inout), polys, poly_stride_limbs, count, start, _stream()))
+
+    def ntt_launch_phase(self, inout, polys, poly_stride_limbs, count, start, inverse, phase):
+        _check(lib().pha_ntt_launch_phase(self._h, _ptr(inout), polys, poly_stride_limbs, count, start, int(inverse),
+                                          int(phase), _stream()))
 
     # DRNSTool ---------------------------------------------------------------------------------
     def modup(self, chain_index, dst, cks):

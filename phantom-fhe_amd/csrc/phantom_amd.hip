@@ -264,13 +264,15 @@ void launch_icol(int epi, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, 
     }
 
 int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stride, const NttRange &r, int epi,
-                const Epilogue &ep, hipStream_t st) {
+                const Epilogue &ep, hipStream_t st, int phases = 3) {
     if (!r.active || !polys) return PHA_OK;
     const dim3 grid(r.active * static_cast<uint32_t>(ctx->n >> 12), static_cast<uint32_t>(polys));
     const NttTables T = ctx->fwd_tables();
+    if (phases & 1)
     DISPATCH_S(ctx->plan.s1, 0, (launch_fcol<6, 3>(grid, st, data, poly_stride, T, r.lm)),
                (launch_fcol<7, 4>(grid, st, data, poly_stride, T, r.lm)),
                (launch_fcol<8, 4>(grid, st, data, poly_stride, T, r.lm)));
+    if (phases & 2)
     DISPATCH_S(ctx->plan.s2, 0, (launch_frow<6, 3>(epi, grid, st, data, poly_stride, T, r.lm, ep)),
                (launch_frow<7, 4>(epi, grid, st, data, poly_stride, T, r.lm, ep)),
                (launch_frow<8, 4>(epi, grid, st, data, poly_stride, T, r.lm, ep)));
@@ -278,13 +280,15 @@ int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stri
 }
 
 int ntt_backward(pha_context *ctx, uint64_t *out, const uint64_t *in, size_t polys, size_t poly_stride,
-                 const NttRange &r, int epi, const Epilogue &ep, hipStream_t st) {
+                 const NttRange &r, int epi, const Epilogue &ep, hipStream_t st, int phases = 3) {
     if (!r.active || !polys) return PHA_OK;
     const dim3 grid(r.active * static_cast<uint32_t>(ctx->n >> 12), static_cast<uint32_t>(polys));
     const NttTables T = ctx->inv_tables();
+    if (phases & 2)
     DISPATCH_S(ctx->plan.s2, 0, (launch_irow<6, 3>(grid, st, out, in, poly_stride, T, r.lm)),
                (launch_irow<7, 4>(grid, st, out, in, poly_stride, T, r.lm)),
                (launch_irow<8, 4>(grid, st, out, in, poly_stride, T, r.lm)));
+    if (phases & 1)
     DISPATCH_S(ctx->plan.s1, 0, (launch_icol<6, 3>(epi, grid, st, out, poly_stride, T, r.lm, ep)),
                (launch_icol<7, 4>(epi, grid, st, out, poly_stride, T, r.lm, ep)),
                (launch_icol<8, 4>(epi, grid, st, out, poly_stride, T, r.lm, ep)));
@@ -717,6 +721,19 @@ int pha_ntt_backward_batched(pha_context *ctx, uint64_t *inout, size_t polys, si
     NttRange r;
     PHA_TRY(make_range(ctx, count, start, 0, 0, 0, 0, r));
     return ntt_backward(ctx, inout, inout, polys, poly_stride_limbs * ctx->n, r, EPI_NONE, Epilogue{}, as_stream(stream));
+}
+
+int pha_ntt_launch_phase(pha_context *ctx, uint64_t *inout, size_t polys, size_t poly_stride_limbs, size_t count,
+                         size_t start, int inverse, int phase, pha_stream_t stream) {
+    REQUIRE_CTX(inout);
+    if (phase != 0 && phase != 1) return fail(PHA_ERR_INVALID_ARGUMENT, "phase must be 0 (column) or 1 (row)");
+    NttRange r;
+    PHA_TRY(make_range(ctx, count, start, 0, 0, 0, 0, r));
+    const int mask = phase == 0 ? 1 : 2;
+    if (inverse)
+        return ntt_backward(ctx, inout, inout, polys, poly_stride_limbs * ctx->n, r, EPI_NONE, Epilogue{},
+                            as_stream(stream), mask);
+    return ntt_forward(ctx, inout, polys, poly_stride_limbs * ctx->n, r, EPI_NONE, Epilogue{}, as_stream(stream), mask);
 }
 
 int pha_modup(pha_context *ctx, size_t chain_index, uint64_t *dst, const uint64_t *cks, pha_stream_t stream) {

@@ -1,0 +1,128 @@
+// Micro-benchmarks that decide the NTT design on gfx950: integer multiply issue rates, the cost
+// of one Shoup butterfly, FP64 FMA rate, and in-place streaming bandwidth at cache-resident and
+// HBM-resident footprints.  Build: hipcc -O3 --offload-arch=gfx950 tools/ubench.hip -o tools/ubench
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+constexpr int ITERS = 4096;
+constexpr int ILP = 8;
+
+template <int OP>
+__global__ __launch_bounds__(256) void alu_kernel(uint64_t *out, uint64_t seed) {
+    uint64_t a[ILP];
+    uint32_t b = static_cast<uint32_t>(seed) | 1u;
+    uint64_t w = seed * 0x9E3779B97F4A7C15ull | 1ull;
+    double fa[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; i++) { a[i] = seed + threadIdx.x * 7 + i * 1315423911ull + blockIdx.x; fa[i] = 1.0 + i + threadIdx.x; }
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) {
+            if (OP == 0) a[i] = static_cast<uint64_t>(static_cast<uint32_t>(a[i])) * b + a[i];                  // v_mad_u64_u32
+            if (OP == 1) a[i] = static_cast<uint32_t>(a[i]) * b;                                                 // v_mul_lo_u32
+            if (OP == 2) a[i] = __umulhi(static_cast<uint32_t>(a[i]), b) + 1;                                    // v_mul_hi_u32
+            if (OP == 3) a[i] = a[i] * w + 1;                                                                    // 64-bit mul lo
+            if (OP == 4) a[i] = __umul64hi(a[i], w) + a[i];                                                      // mulhi64
+            if (OP == 5) { uint64_t h = __umul64hi(a[i], w); a[i] = a[i] * (w >> 3) - h * 0x0FFFFFFFFFFC0001ull; } // shoup lazy
+            if (OP == 6) fa[i] = __fma_rn(fa[i], 1.0000001, 0.5);                                                // v_fma_f64
+            if (OP == 7) a[i] = a[i] + w;                                                                        // 64-bit add
+            if (OP == 8) a[i] = static_cast<uint32_t>(a[i]) + b;                                                 // 32-bit add
+            if (OP == 9) a[i] = __mul24(static_cast<int>(a[i]), static_cast<int>(b));                             // v_mul_i32_i24
+        }
+    }
+    uint64_t r = 0;
+#pragma unroll
+    for (int i = 0; i < ILP; i++) r += a[i] + static_cast<uint64_t>(fa[i]);
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
+__global__ __launch_bounds__(256) void stream_rw_kernel(ulonglong2 *buf, size_t n16) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += gridDim.x * 256ull) {
+        ulonglong2 v = buf[i];
+        v.x += 1;
+        v.y ^= 3;
+        buf[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void stream_rw8_kernel(uint64_t *buf, size_t n8) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n8; i += gridDim.x * 256ull) buf[i] += 1;
+}
+
+template <int OP>
+int run_alu(const char *name, uint64_t *d_out, double ops_per_iter) {
+    const int blocks = 256 * 8;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(alu_kernel<OP>, dim3(blocks), dim3(256), 0, 0, d_out, 12345ull);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < 5; r++) hipLaunchKernelGGL(alu_kernel<OP>, dim3(blocks), dim3(256), 0, 0, d_out, 12345ull + r);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double lane_ops = 5.0 * blocks * 256.0 * ITERS * ILP * ops_per_iter;
+    printf("%-28s %8.3f ms  %8.2f T lane-ops/s  (%.2f cycles per wave-instr per SIMD @2.4GHz)\n", name, ms,
+           lane_ops / (ms * 1e-3) / 1e12, 1024.0 * 2.4e9 * 64 / (lane_ops / (ms * 1e-3)));
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1) {
+        // calibration mode for the FETCH_SIZE / WRITE_SIZE counters: known byte counts
+        // (512 MiB read + 512 MiB written per launch), 3 launches of each access width
+        const size_t bytes = 512ull << 20;
+        void *buf;
+        CHECK(hipMalloc(&buf, bytes));
+        CHECK(hipMemset(buf, 1, bytes));
+        for (int r = 0; r < 3; r++) hipLaunchKernelGGL(stream_rw_kernel, dim3(8192), dim3(256), 0, 0, (ulonglong2 *)buf, bytes / 16);
+        for (int r = 0; r < 3; r++) hipLaunchKernelGGL(stream_rw8_kernel, dim3(8192), dim3(256), 0, 0, (uint64_t *)buf, bytes / 8);
+        CHECK(hipDeviceSynchronize());
+        printf("calibration: 536870912 bytes read and written per launch\n");
+        return 0;
+    }
+    uint64_t *d_out;
+    CHECK(hipMalloc(&d_out, 256 * 8 * 256 * sizeof(uint64_t)));
+    run_alu<0>("v_mad_u64_u32", d_out, 1);
+    run_alu<1>("v_mul_lo_u32", d_out, 1);
+    run_alu<2>("v_mul_hi_u32(+add)", d_out, 1);
+    run_alu<3>("mul64 lo (+add)", d_out, 1);
+    run_alu<4>("mulhi64 (+add)", d_out, 1);
+    run_alu<5>("shoup lazy modmul", d_out, 1);
+    run_alu<6>("v_fma_f64", d_out, 1);
+    run_alu<7>("add64", d_out, 1);
+    run_alu<8>("add32", d_out, 1);
+    run_alu<9>("v_mul_i32_i24", d_out, 1);
+
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (size_t mib : {36ull, 72ull, 144ull, 512ull, 2048ull}) {
+        const size_t bytes = mib << 20;
+        void *buf;
+        CHECK(hipMalloc(&buf, bytes));
+        CHECK(hipMemset(buf, 1, bytes));
+        for (int variant = 0; variant < 2; variant++) {
+            const int reps = mib <= 144 ? 50 : 10;
+            for (int grid : {2048, 8192}) {
+                auto launch = [&]() {
+                    if (variant == 0) hipLaunchKernelGGL(stream_rw_kernel, dim3(grid), dim3(256), 0, 0, (ulonglong2 *)buf, bytes / 16);
+                    else hipLaunchKernelGGL(stream_rw8_kernel, dim3(grid), dim3(256), 0, 0, (uint64_t *)buf, bytes / 8);
+                };
+                launch(); launch();
+                CHECK(hipDeviceSynchronize());
+                CHECK(hipEventRecord(e0));
+                for (int r = 0; r < reps; r++) launch();
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                printf("in-place rw %4zu MiB %s grid %5d: %8.2f us/launch  %7.2f TB/s (read+write)\n", mib,
+                       variant == 0 ? "16B/lane" : " 8B/lane", grid, 1e3 * ms / reps, 2.0 * bytes * reps / (ms * 1e-3) / 1e12);
+            }
+        }
+        CHECK(hipFree(buf));
+    }
+    return 0;
+}
