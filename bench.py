@@ -47,6 +47,42 @@ def parse():
     return ap.parse_args()
 
 
+def shard_units(total_units, world, rank):
+    """Independent units (ciphertexts, config 4; batches here) are dealt to ranks in contiguous blocks,
+    the first `total % world` ranks taking one more; no data-path collective."""
+    base, extra = divmod(total_units, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def dist_setup(backend):
+    """Returns (rank, world, local_rank, dist or None); RANK/WORLD_SIZE/MASTER_* come from the launcher."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        dist.init_process_group(backend, **kw)
+    return rank, world, local_rank, dist
+
+
+def max_over_ranks(elapsed, dist, device):
+    """Whole-job time = slowest rank."""
+    if dist is None:
+        return elapsed
+    import torch
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def aggregate_value(units_per_rank_step, steps, world, elapsed):
+    return world * units_per_rank_step * steps / elapsed
+
+
 def event_time_ms(torch, fn, reps):
     """Average duration of fn() over reps back-to-back launches, HIP events on the current stream."""
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -103,12 +139,7 @@ def main():
 
     import phantom_fhe_amd as pha
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    rank, world, local_rank, dist = dist_setup("nccl")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
 
@@ -138,15 +169,12 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dist, "cuda")
     # size-independent property at full size: the round trips returned the input bit-for-bit
     assert torch.equal(buf, orig), "INTT(NTT(x)) != x after the timed region"
 
     units_per_step = 2 * POLYS * LIMBS
-    value = world * units_per_step * args.steps / elapsed
+    value = aggregate_value(units_per_step, args.steps, world, elapsed)
     out = {
         "metric": "RNS-NTT limb-transforms/s @N=2^16 (forward+inverse, 36 limbs x 2 polys per GPU)",
         "value": value, "unit": "limb-transforms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

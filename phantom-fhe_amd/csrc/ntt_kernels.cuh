@@ -27,6 +27,8 @@ struct LimbMap {
     uint32_t size_QP, size_P;       // size_P > 0: last size_P limbs of the range use key-level table
                                     // indices size_QP - size_P + k (src/ntt/fntt_2d.cu:433-436)
     uint32_t excl_start, excl_end;  // limbs skipped (src/ntt/ntt_modup.cu:422); empty if start >= end
+    uint32_t active;                // limbs actually transformed = count - |excluded|
+    uint32_t polys;                 // buffers [polys][...] handled by this launch
 };
 
 struct NttTables {
@@ -53,6 +55,22 @@ __device__ __forceinline__ void resolve_limb(const LimbMap &m, uint32_t li, uint
     twr = m.start + li;
     if (m.excl_end > m.excl_start && twr >= m.excl_start) twr += m.excl_end - m.excl_start;
     tidx = (m.size_P && twr >= m.start + m.count - m.size_P) ? m.size_QP - (m.start + m.count - twr) : twr;
+}
+
+// Work decomposition of a launch: one workgroup per (poly, limb, tile).  Workgroups b and b + 8
+// share an XCD (round-robin dispatch), so the polys of one tile are made consecutive members of
+// one XCD's sequence: they read the same twiddles and the second read hits that XCD's L2.
+// Placement is a speed matter only.
+__device__ __forceinline__ void decode_block(uint32_t b, uint32_t polys, uint32_t total_tiles, uint32_t &poly,
+                                             uint32_t &tile) {
+    if ((total_tiles & 7u) == 0) {
+        const uint32_t x = b & 7u, u = b >> 3;
+        poly = u % polys;
+        tile = (u / polys) * 8 + x;
+    } else {
+        poly = b % polys;
+        tile = b / polys;
+    }
 }
 
 struct CanonTw {
@@ -125,10 +143,12 @@ __global__ __launch_bounds__(kThreads) void fntt_col_kernel(uint64_t *data, size
     constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
     __shared__ uint64_t lds[kLdsWords];
     const uint32_t n = 1u << T.log_n, n2 = n >> S1, tiles = n >> 12;
-    const uint32_t li = blockIdx.x / tiles, ti = blockIdx.x % tiles;
+    uint32_t poly, tile;
+    decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
+    const uint32_t li = tile / tiles, ti = tile % tiles;
     uint32_t twr, tidx;
     resolve_limb(lm, li, twr, tidx);
-    uint64_t *base = data + blockIdx.y * poly_stride + static_cast<size_t>(twr) * n + ti * C;
+    uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + ti * C;
     const uint64_t q = T.mod[tidx].value, q2 = q << 1;
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     const uint32_t t = threadIdx.x;
@@ -165,11 +185,13 @@ __global__ __launch_bounds__(kThreads) void fntt_row_kernel(uint64_t *data, size
     constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
     __shared__ uint64_t lds[kLdsWords];
     const uint32_t n = 1u << T.log_n, n1 = n >> S2, tiles = n >> 12;
-    const uint32_t li = blockIdx.x / tiles, ti = blockIdx.x % tiles;
+    uint32_t poly, tile;
+    decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
+    const uint32_t li = tile / tiles, ti = tile % tiles;
     uint32_t twr, tidx;
     resolve_limb(lm, li, twr, tidx);
     const size_t limb_off = static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
-    uint64_t *base = data + blockIdx.y * poly_stride + limb_off;
+    uint64_t *base = data + poly * poly_stride + limb_off;
     const DModulus mod = T.mod[tidx];
     const uint64_t q = mod.value, q2 = q << 1;
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
@@ -205,9 +227,9 @@ __global__ __launch_bounds__(kThreads) void fntt_row_kernel(uint64_t *data, size
     const uint64_t *sub = nullptr, *addend = nullptr;
     uint64_t cst = 0, cst_shoup = 0;
     if (EPI != EPI_NONE) {
-        out = ep.out + blockIdx.y * ep.out_poly_stride + limb_off;
-        sub = ep.sub + blockIdx.y * ep.sub_poly_stride + limb_off;
-        if (EPI == EPI_SUB_MUL_ADD) addend = ep.addend + blockIdx.y * ep.out_poly_stride + limb_off;
+        out = ep.out + poly * ep.out_poly_stride + limb_off;
+        sub = ep.sub + poly * ep.sub_poly_stride + limb_off;
+        if (EPI == EPI_SUB_MUL_ADD) addend = ep.addend + poly * ep.out_poly_stride + limb_off;
         cst = ep.cst[twr];
         cst_shoup = ep.cst_shoup[twr];
     }
@@ -242,10 +264,12 @@ __global__ __launch_bounds__(kThreads) void intt_row_kernel(uint64_t *out, const
     constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
     __shared__ uint64_t lds[kLdsWords];
     const uint32_t n = 1u << T.log_n, n1 = n >> S2, tiles = n >> 12;
-    const uint32_t li = blockIdx.x / tiles, ti = blockIdx.x % tiles;
+    uint32_t poly, tile;
+    decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
+    const uint32_t li = tile / tiles, ti = tile % tiles;
     uint32_t twr, tidx;
     resolve_limb(lm, li, twr, tidx);
-    const size_t off = blockIdx.y * poly_stride + static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
+    const size_t off = poly * poly_stride + static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
     const uint64_t *src = in + off;
     uint64_t *dst = out + off;
     const uint64_t q = T.mod[tidx].value, q2 = q << 1;
@@ -295,10 +319,12 @@ __global__ __launch_bounds__(kThreads) void intt_col_kernel(uint64_t *data, size
     constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
     __shared__ uint64_t lds[kLdsWords];
     const uint32_t n = 1u << T.log_n, n2 = n >> S1, tiles = n >> 12;
-    const uint32_t li = blockIdx.x / tiles, ti = blockIdx.x % tiles;
+    uint32_t poly, tile;
+    decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
+    const uint32_t li = tile / tiles, ti = tile % tiles;
     uint32_t twr, tidx;
     resolve_limb(lm, li, twr, tidx);
-    uint64_t *base = data + blockIdx.y * poly_stride + static_cast<size_t>(twr) * n + ti * C;
+    uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + ti * C;
     const uint64_t q = T.mod[tidx].value, q2 = q << 1;
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     const uint32_t t = threadIdx.x;

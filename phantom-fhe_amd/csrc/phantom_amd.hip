@@ -218,9 +218,10 @@ int make_range(const pha_context *ctx, size_t count, size_t start, size_t size_Q
     } else {
         excl_s = excl_e = 0;
     }
-    r.lm = LimbMap{static_cast<uint32_t>(start), static_cast<uint32_t>(count), static_cast<uint32_t>(size_QP),
-                   static_cast<uint32_t>(size_P), static_cast<uint32_t>(excl_s), static_cast<uint32_t>(excl_e)};
     r.active = static_cast<uint32_t>(count) - len;
+    r.lm = LimbMap{static_cast<uint32_t>(start), static_cast<uint32_t>(count), static_cast<uint32_t>(size_QP),
+                   static_cast<uint32_t>(size_P), static_cast<uint32_t>(excl_s), static_cast<uint32_t>(excl_e),
+                   r.active, 1u};
     return PHA_OK;
 }
 
@@ -266,32 +267,36 @@ void launch_icol(int epi, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, 
 int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stride, const NttRange &r, int epi,
                 const Epilogue &ep, hipStream_t st, int phases = 3) {
     if (!r.active || !polys) return PHA_OK;
-    const dim3 grid(r.active * static_cast<uint32_t>(ctx->n >> 12), static_cast<uint32_t>(polys));
+    const dim3 grid(r.active * static_cast<uint32_t>(ctx->n >> 12) * static_cast<uint32_t>(polys));
     const NttTables T = ctx->fwd_tables();
+    NttRange rr = r;
+    rr.lm.polys = static_cast<uint32_t>(polys);
     if (phases & 1)
-    DISPATCH_S(ctx->plan.s1, 0, (launch_fcol<6, 3>(grid, st, data, poly_stride, T, r.lm)),
-               (launch_fcol<7, 4>(grid, st, data, poly_stride, T, r.lm)),
-               (launch_fcol<8, 4>(grid, st, data, poly_stride, T, r.lm)));
+    DISPATCH_S(ctx->plan.s1, 0, (launch_fcol<6, 3>(grid, st, data, poly_stride, T, rr.lm)),
+               (launch_fcol<7, 4>(grid, st, data, poly_stride, T, rr.lm)),
+               (launch_fcol<8, 4>(grid, st, data, poly_stride, T, rr.lm)));
     if (phases & 2)
-    DISPATCH_S(ctx->plan.s2, 0, (launch_frow<6, 3>(epi, grid, st, data, poly_stride, T, r.lm, ep)),
-               (launch_frow<7, 4>(epi, grid, st, data, poly_stride, T, r.lm, ep)),
-               (launch_frow<8, 4>(epi, grid, st, data, poly_stride, T, r.lm, ep)));
+    DISPATCH_S(ctx->plan.s2, 0, (launch_frow<6, 3>(epi, grid, st, data, poly_stride, T, rr.lm, ep)),
+               (launch_frow<7, 4>(epi, grid, st, data, poly_stride, T, rr.lm, ep)),
+               (launch_frow<8, 4>(epi, grid, st, data, poly_stride, T, rr.lm, ep)));
     return check_launch("forward NTT");
 }
 
 int ntt_backward(pha_context *ctx, uint64_t *out, const uint64_t *in, size_t polys, size_t poly_stride,
                  const NttRange &r, int epi, const Epilogue &ep, hipStream_t st, int phases = 3) {
     if (!r.active || !polys) return PHA_OK;
-    const dim3 grid(r.active * static_cast<uint32_t>(ctx->n >> 12), static_cast<uint32_t>(polys));
+    const dim3 grid(r.active * static_cast<uint32_t>(ctx->n >> 12) * static_cast<uint32_t>(polys));
     const NttTables T = ctx->inv_tables();
+    NttRange rr = r;
+    rr.lm.polys = static_cast<uint32_t>(polys);
     if (phases & 2)
-    DISPATCH_S(ctx->plan.s2, 0, (launch_irow<6, 3>(grid, st, out, in, poly_stride, T, r.lm)),
-               (launch_irow<7, 4>(grid, st, out, in, poly_stride, T, r.lm)),
-               (launch_irow<8, 4>(grid, st, out, in, poly_stride, T, r.lm)));
+    DISPATCH_S(ctx->plan.s2, 0, (launch_irow<6, 3>(grid, st, out, in, poly_stride, T, rr.lm)),
+               (launch_irow<7, 4>(grid, st, out, in, poly_stride, T, rr.lm)),
+               (launch_irow<8, 4>(grid, st, out, in, poly_stride, T, rr.lm)));
     if (phases & 1)
-    DISPATCH_S(ctx->plan.s1, 0, (launch_icol<6, 3>(epi, grid, st, out, poly_stride, T, r.lm, ep)),
-               (launch_icol<7, 4>(epi, grid, st, out, poly_stride, T, r.lm, ep)),
-               (launch_icol<8, 4>(epi, grid, st, out, poly_stride, T, r.lm, ep)));
+    DISPATCH_S(ctx->plan.s1, 0, (launch_icol<6, 3>(epi, grid, st, out, poly_stride, T, rr.lm, ep)),
+               (launch_icol<7, 4>(epi, grid, st, out, poly_stride, T, rr.lm, ep)),
+               (launch_icol<8, 4>(epi, grid, st, out, poly_stride, T, rr.lm, ep)));
     return check_launch("inverse NTT");
 }
 
