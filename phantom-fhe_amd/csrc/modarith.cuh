@@ -58,6 +58,16 @@ __device__ __forceinline__ void add128(u128_t &acc, const u128_t &x) {
     acc.lo = lo;
 }
 
+__device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return (static_cast<uint64_t>(hi) << 32) | lo; }
+
+// High word of a 64x64 product without the low x low partial product and without the carries of
+// the cross terms: true - 2 <= result <= true.  2 x v_mul_hi_u32 + 1 x v_mad_u64_u32.
+__device__ __forceinline__ uint64_t mulhi64_approx(uint64_t a, uint64_t b) {
+    const uint32_t a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
+    const uint64_t cross = static_cast<uint64_t>(__umulhi(a0, b1)) + __umulhi(a1, b0);
+    return mad32(a1, b1, cross);
+}
+
 // x in [0, 2m) -> [0, m)   (include/uintmodmath.cuh:18-21)
 __device__ __forceinline__ uint64_t csub(uint64_t x, uint64_t m) { return x >= m ? x - m : x; }
 
@@ -92,6 +102,54 @@ __device__ __forceinline__ uint64_t barrett128(const u128_t &x, const DModulus &
 
 __device__ __forceinline__ uint64_t mul_barrett(uint64_t a, uint64_t b, const DModulus &m) {
     return barrett128(mul64x64(a, b), m);
+}
+
+// Per-limb constants of the lazy butterflies: q, 4q and 2^64 - q (so that x*w - h*q becomes a
+// chain of multiply-adds modulo 2^64).
+struct LazyMod {
+    uint64_t q, q4, nq, q8, nq8;
+    __device__ __forceinline__ explicit LazyMod(uint64_t q_)
+        : q(q_), q4(q_ << 2), nq(0 - q_), q8(q_ << 3), nq8(0 - (q_ << 3)) {}
+};
+
+// x * w mod q in [0, 4q) for ANY 64-bit x, w < q < 2^61: Shoup's multiplication with the
+// approximate quotient above (the quotient is at most 3 too small: one from Shoup's floor, two
+// from mulhi64_approx).  9 integer multiplies: 3 for the quotient, 2 v_mad_u64_u32 for the low
+// words and 4 v_mul_lo_u32 for the cross terms of the low 64 bits.
+__device__ __forceinline__ uint64_t mul_shoup_lazy4(uint64_t x, const tw_t &w, const LazyMod &m) {
+    const uint64_t h = mulhi64_approx(x, w.y);
+    const uint32_t x0 = lo32(x), x1 = hi32(x), h0 = lo32(h), h1 = hi32(h);
+    const uint32_t w0 = lo32(w.x), w1 = hi32(w.x), n0 = lo32(m.nq), n1 = hi32(m.nq);
+    const uint64_t acc = mad32(h0, n0, mad32(x0, w0, 0));
+    const uint32_t hi = hi32(acc) + x0 * w1 + x1 * w0 + h0 * n1 + h1 * n0;
+    return pack64(lo32(acc), hi);
+}
+
+// forward butterfly on the wide lazy range: x,y in [0,8q) -> [0,8q)  (8q < 2^64 since q < 2^61)
+__device__ __forceinline__ void ct_butterfly8(uint64_t &x, uint64_t &y, const tw_t &w, const LazyMod &m) {
+    const uint64_t t = mul_shoup_lazy4(y, w, m);
+    const uint64_t u = csub(x, m.q4);
+    x = u + t;
+    y = u + (m.q4 - t);
+}
+
+// forward butterfly for q < 2^60 (16q < 2^64): the conditional subtraction (the most expensive
+// non-multiply part: a 64-bit compare plus selects) runs only on every other stage.
+//   CS stage:     x,y in [0,16q): u = x - 8q if x >= 8q  -> outputs in [0,12q)
+//   non-CS stage: x,y in [0,12q)                         -> outputs in [0,16q)
+template <bool CS>
+__device__ __forceinline__ void ct_butterfly16(uint64_t &x, uint64_t &y, const tw_t &w, const LazyMod &m) {
+    const uint64_t t = mul_shoup_lazy4(y, w, m);
+    const uint64_t u = CS ? x + (x >= m.q8 ? m.nq8 : 0ull) : x;
+    x = u + t;
+    y = u + (m.q4 - t);
+}
+
+// inverse butterfly: x,y in [0,4q) -> [0,4q)
+__device__ __forceinline__ void gs_butterfly4(uint64_t &x, uint64_t &y, const tw_t &w, const LazyMod &m) {
+    const uint64_t d = x + (m.q4 - y);
+    x = csub(x + y, m.q4);
+    y = mul_shoup_lazy4(d, w, m);
 }
 
 // Harvey forward butterfly, x,y in [0,4q) -> [0,4q)  (include/butterfly.cuh:10-22)

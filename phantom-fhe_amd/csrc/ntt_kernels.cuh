@@ -85,19 +85,28 @@ struct LastPassTw {
     __device__ __forceinline__ tw_t operator()(int s, int jb) const { return base[((1 << s) - 1 + jb) * 64]; }
 };
 
-// radix-2^R decimation-in-time block: stage s uses twiddle node*2^s + jb on sub-block jb
-template <int R, class Tw>
-__device__ __forceinline__ void ct_radix(uint64_t (&x)[1 << R], const Tw &tw, uint64_t q, uint64_t q2) {
+// radix-2^R decimation-in-time block: stage s uses twiddle node*2^s + jb on sub-block jb.
+// G0 = index of the block's first stage within its kernel.  NARROW (every modulus < 2^60): lazy
+// range [0,16q), conditional subtraction on even kernel-local stages only; otherwise range
+// [0,8q) with a conditional subtraction every stage.
+template <int R, int G0, bool NARROW, class Tw>
+__device__ __forceinline__ void ct_radix(uint64_t (&x)[1 << R], const Tw &tw, const LazyMod &m) {
 #pragma unroll
     for (int s = 0; s < R; s++) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int half = 1 << (R - 1 - s);
 #pragma unroll
         for (int jb = 0; jb < (1 << s); jb++) {
             const tw_t w = tw(s, jb);
 #pragma unroll
-            for (int i = 0; i < half; i++) ct_butterfly(x[jb * 2 * half + i], x[jb * 2 * half + half + i], w, q, q2);
+            for (int i = 0; i < half; i++) {
+                uint64_t &a = x[jb * 2 * half + i], &b = x[jb * 2 * half + half + i];
+                if (!NARROW)
+                    ct_butterfly8(a, b, w, m);
+                else if (((G0 + s) & 1) == 0)
+                    ct_butterfly16<true>(a, b, w, m);
+                else
+                    ct_butterfly16<false>(a, b, w, m);
+            }
         }
     }
 }
@@ -105,7 +114,7 @@ __device__ __forceinline__ void ct_radix(uint64_t (&x)[1 << R], const Tw &tw, ui
 // inverse block; LAST: the final stage multiplies the sum half by N^-1 (the difference half gets
 // it through itw[1], src/util/ntt.cu:53-55) and reduces everything to [0,q)
 template <int R, bool LAST, class Tw>
-__device__ __forceinline__ void gs_radix(uint64_t (&x)[1 << R], const Tw &tw, uint64_t q, uint64_t q2, uint64_t n_inv = 0,
+__device__ __forceinline__ void gs_radix(uint64_t (&x)[1 << R], const Tw &tw, const LazyMod &m, uint64_t n_inv = 0,
                                          uint64_t n_inv_shoup = 0) {
 #pragma unroll
     for (int s = R - 1; s >= (LAST ? 1 : 0); s--) {
@@ -114,7 +123,7 @@ __device__ __forceinline__ void gs_radix(uint64_t (&x)[1 << R], const Tw &tw, ui
         for (int jb = 0; jb < (1 << s); jb++) {
             const tw_t w = tw(s, jb);
 #pragma unroll
-            for (int i = 0; i < half; i++) gs_butterfly(x[jb * 2 * half + i], x[jb * 2 * half + half + i], w, q, q2);
+            for (int i = 0; i < half; i++) gs_butterfly4(x[jb * 2 * half + i], x[jb * 2 * half + half + i], w, m);
         }
     }
     if (LAST) {
@@ -123,22 +132,29 @@ __device__ __forceinline__ void gs_radix(uint64_t (&x)[1 << R], const Tw &tw, ui
 #pragma unroll
         for (int i = 0; i < half; i++) {
             const uint64_t a = x[i], b = x[half + i];
-            x[i] = csub(mul_shoup_lazy(a + b, n_inv, n_inv_shoup, q), q);
-            x[half + i] = csub(mul_shoup_lazy(a + q2 - b, w.x, w.y, q), q);
+            // exact-quotient Shoup here: one conditional subtraction lands in [0,q)
+            x[i] = csub(mul_shoup_lazy(a + b, n_inv, n_inv_shoup, m.q), m.q);
+            x[half + i] = csub(mul_shoup_lazy(a + (m.q4 - b), w.x, w.y, m.q), m.q);
         }
     }
 }
 
+// LDS images are padded against bank conflicts (measured: an unpadded XOR-swizzled 32 KiB image
+// that admits five workgroups per CU was not faster).
+// Column tile [row][C cols]: with C = 16 a row is half a 256-B bank row; shift every 2^RB-row
+// group by one row so that the second pass's half-waves hit both halves.
 template <int C, int RB>
 __device__ __forceinline__ uint32_t lds_col(uint32_t r, uint32_t c) {
     return r * C + c + (C == 16 ? (r >> RB) * 16 : 0);
 }
+// Row tile: 16 B of padding per 128 B so that the last pass's ds_read_b128 (lane stride 128 B)
+// is conflict-free.
 __device__ __forceinline__ uint32_t lds_row(uint32_t e) { return e + ((e >> 4) << 1); }
 
 // ---------------------------------------------------------------------------------------------
 // forward, column phase: stages m = 1 .. 2^(S1-1)
 // ---------------------------------------------------------------------------------------------
-template <int S1, int RA>
+template <int S1, int RA, bool NARROW>
 __global__ __launch_bounds__(kThreads) void fntt_col_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm) {
     constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
     __shared__ uint64_t lds[kLdsWords];
@@ -149,7 +165,8 @@ __global__ __launch_bounds__(kThreads) void fntt_col_kernel(uint64_t *data, size
     uint32_t twr, tidx;
     resolve_limb(lm, li, twr, tidx);
     uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + ti * C;
-    const uint64_t q = T.mod[tidx].value, q2 = q << 1;
+    const uint64_t q = T.mod[tidx].value;
+    const LazyMod lmod(q);
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     const uint32_t t = threadIdx.x;
 
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(kThreads) void fntt_col_kernel(uint64_t *data, size
         uint64_t x[1 << RA];
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) x[j] = base[static_cast<size_t>((j << RB) | r_lo) * n2 + c];
-        ct_radix<RA>(x, CanonTw{tw, 1u}, q, q2);
+        ct_radix<RA, 0, NARROW>(x, CanonTw{tw, 1u}, lmod);
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) lds[lds_col<C, RB>((j << RB) | r_lo, c)] = x[j];
     }
@@ -170,7 +187,7 @@ __global__ __launch_bounds__(kThreads) void fntt_col_kernel(uint64_t *data, size
         uint64_t x[1 << RB];
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) x[j] = lds[lds_col<C, RB>((r_hi << RB) | j, c)];
-        ct_radix<RB>(x, CanonTw{tw, (1u << RA) + r_hi}, q, q2);
+        ct_radix<RB, RA, NARROW>(x, CanonTw{tw, (1u << RA) + r_hi}, lmod);
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) base[static_cast<size_t>((r_hi << RB) | j) * n2 + c] = x[j];
     }
@@ -179,7 +196,7 @@ __global__ __launch_bounds__(kThreads) void fntt_col_kernel(uint64_t *data, size
 // ---------------------------------------------------------------------------------------------
 // forward, row phase: stages m = 2^S1 .. N/2, final reduction to [0,q), optional fused epilogue
 // ---------------------------------------------------------------------------------------------
-template <int S2, int RA, int EPI>
+template <int S2, int RA, int EPI, bool NARROW>
 __global__ __launch_bounds__(kThreads) void fntt_row_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm,
                                                             Epilogue ep) {
     constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
@@ -193,7 +210,8 @@ __global__ __launch_bounds__(kThreads) void fntt_row_kernel(uint64_t *data, size
     const size_t limb_off = static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
     uint64_t *base = data + poly * poly_stride + limb_off;
     const DModulus mod = T.mod[tidx];
-    const uint64_t q = mod.value, q2 = q << 1;
+    const uint64_t q = mod.value;
+    const LazyMod lmod(q);
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     const uint32_t t = threadIdx.x;
 
@@ -203,7 +221,7 @@ __global__ __launch_bounds__(kThreads) void fntt_row_kernel(uint64_t *data, size
         uint64_t x[1 << RA];
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) x[j] = base[a * L + ((j << RB) | b_lo)];
-        ct_radix<RA>(x, CanonTw{tw, n1 + ti * RW + a}, q, q2);
+        ct_radix<RA, 0, NARROW>(x, CanonTw{tw, n1 + ti * RW + a}, lmod);
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) lds[lds_row(a * L + ((j << RB) | b_lo))] = x[j];
     }
@@ -217,9 +235,13 @@ __global__ __launch_bounds__(kThreads) void fntt_row_kernel(uint64_t *data, size
         for (int j = 0; j < (1 << RB); j++) x[j] = lds[lds_row(e0 + j)];
         const tw_t *twd = T.twD + static_cast<size_t>(tidx) * T.twD_stride +
                           static_cast<size_t>(ggid >> 6) * (((1 << RB) - 1) * 64) + (ggid & 63);
-        ct_radix<RB>(x, LastPassTw<RB>{twd}, q, q2);
+        ct_radix<RB, RA, NARROW>(x, LastPassTw<RB>{twd}, lmod);
 #pragma unroll
-        for (int j = 0; j < (1 << RB); j++) lds[lds_row(e0 + j)] = csub(csub(x[j], q2), q);
+        for (int j = 0; j < (1 << RB); j++) {
+            uint64_t v = x[j];
+            if (NARROW) v = csub(v, lmod.q8);
+            lds[lds_row(e0 + j)] = csub(csub(csub(v, lmod.q4), q << 1), q);
+        }
     }
     __syncthreads();
 
@@ -272,7 +294,8 @@ __global__ __launch_bounds__(kThreads) void intt_row_kernel(uint64_t *out, const
     const size_t off = poly * poly_stride + static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
     const uint64_t *src = in + off;
     uint64_t *dst = out + off;
-    const uint64_t q = T.mod[tidx].value, q2 = q << 1;
+    const uint64_t q = T.mod[tidx].value;
+    const LazyMod lmod(q);
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     const uint32_t t = threadIdx.x;
 
@@ -293,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void intt_row_kernel(uint64_t *out, const
         for (int j = 0; j < (1 << RB); j++) x[j] = lds[lds_row(e0 + j)];
         const tw_t *twd = T.twD + static_cast<size_t>(tidx) * T.twD_stride +
                           static_cast<size_t>(ggid >> 6) * (((1 << RB) - 1) * 64) + (ggid & 63);
-        gs_radix<RB, false>(x, LastPassTw<RB>{twd}, q, q2);
+        gs_radix<RB, false>(x, LastPassTw<RB>{twd}, lmod);
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) lds[lds_row(e0 + j)] = x[j];
     }
@@ -304,7 +327,7 @@ __global__ __launch_bounds__(kThreads) void intt_row_kernel(uint64_t *out, const
         uint64_t x[1 << RA];
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) x[j] = lds[lds_row(a * L + ((j << RB) | b_lo))];
-        gs_radix<RA, false>(x, CanonTw{tw, n1 + ti * RW + a}, q, q2);
+        gs_radix<RA, false>(x, CanonTw{tw, n1 + ti * RW + a}, lmod);
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) dst[a * L + ((j << RB) | b_lo)] = x[j];
     }
@@ -325,7 +348,8 @@ __global__ __launch_bounds__(kThreads) void intt_col_kernel(uint64_t *data, size
     uint32_t twr, tidx;
     resolve_limb(lm, li, twr, tidx);
     uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + ti * C;
-    const uint64_t q = T.mod[tidx].value, q2 = q << 1;
+    const uint64_t q = T.mod[tidx].value;
+    const LazyMod lmod(q);
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     const uint32_t t = threadIdx.x;
 
@@ -335,7 +359,7 @@ __global__ __launch_bounds__(kThreads) void intt_col_kernel(uint64_t *data, size
         uint64_t x[1 << RB];
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) x[j] = base[static_cast<size_t>((r_hi << RB) | j) * n2 + c];
-        gs_radix<RB, false>(x, CanonTw{tw, (1u << RA) + r_hi}, q, q2);
+        gs_radix<RB, false>(x, CanonTw{tw, (1u << RA) + r_hi}, lmod);
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) lds[lds_col<C, RB>((r_hi << RB) | j, c)] = x[j];
     }
@@ -352,7 +376,7 @@ __global__ __launch_bounds__(kThreads) void intt_col_kernel(uint64_t *data, size
         uint64_t x[1 << RA];
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) x[j] = lds[lds_col<C, RB>((j << RB) | r_lo, c)];
-        gs_radix<RA, true>(x, CanonTw{tw, 1u}, q, q2, n_inv, n_inv_shoup);
+        gs_radix<RA, true>(x, CanonTw{tw, 1u}, lmod, n_inv, n_inv_shoup);
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) {
             uint64_t v = x[j];

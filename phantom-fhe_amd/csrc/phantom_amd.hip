@@ -111,6 +111,7 @@ struct pha_context {
     int log_n = 0;
     size_t n = 0, size_QP = 0, size_P = 0, size_Q = 0;
     NttPlan plan{};
+    bool narrow = false;  // every modulus < 2^60: forward butterflies use the 16q lazy range
     std::vector<uint64_t> moduli;
     std::vector<LimbTables> host_tables;
     DevBuf<DModulus> d_mod;
@@ -226,22 +227,33 @@ int make_range(const pha_context *ctx, size_t count, size_t start, size_t size_Q
 }
 
 template <int S, int RA>
-void launch_fcol(dim3 grid, hipStream_t st, uint64_t *data, size_t ps, const NttTables &T, const LimbMap &lm) {
-    hipLaunchKernelGGL((fntt_col_kernel<S, RA>), grid, dim3(kThreads), 0, st, data, ps, T, lm);
+void launch_fcol(bool narrow, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, const NttTables &T, const LimbMap &lm) {
+    if (narrow)
+        hipLaunchKernelGGL((fntt_col_kernel<S, RA, true>), grid, dim3(kThreads), 0, st, data, ps, T, lm);
+    else
+        hipLaunchKernelGGL((fntt_col_kernel<S, RA, false>), grid, dim3(kThreads), 0, st, data, ps, T, lm);
 }
-template <int S, int RA>
-void launch_frow(int epi, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, const NttTables &T, const LimbMap &lm,
-                 const Epilogue &ep) {
+template <int S, int RA, bool NARROW>
+void launch_frow_n(int epi, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, const NttTables &T, const LimbMap &lm,
+                   const Epilogue &ep) {
     switch (epi) {
         case EPI_SUB_MUL:
-            hipLaunchKernelGGL((fntt_row_kernel<S, RA, EPI_SUB_MUL>), grid, dim3(kThreads), 0, st, data, ps, T, lm, ep);
+            hipLaunchKernelGGL((fntt_row_kernel<S, RA, EPI_SUB_MUL, NARROW>), grid, dim3(kThreads), 0, st, data, ps, T, lm, ep);
             break;
         case EPI_SUB_MUL_ADD:
-            hipLaunchKernelGGL((fntt_row_kernel<S, RA, EPI_SUB_MUL_ADD>), grid, dim3(kThreads), 0, st, data, ps, T, lm, ep);
+            hipLaunchKernelGGL((fntt_row_kernel<S, RA, EPI_SUB_MUL_ADD, NARROW>), grid, dim3(kThreads), 0, st, data, ps, T, lm, ep);
             break;
         default:
-            hipLaunchKernelGGL((fntt_row_kernel<S, RA, EPI_NONE>), grid, dim3(kThreads), 0, st, data, ps, T, lm, ep);
+            hipLaunchKernelGGL((fntt_row_kernel<S, RA, EPI_NONE, NARROW>), grid, dim3(kThreads), 0, st, data, ps, T, lm, ep);
     }
+}
+template <int S, int RA>
+void launch_frow(bool narrow, int epi, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, const NttTables &T,
+                 const LimbMap &lm, const Epilogue &ep) {
+    if (narrow)
+        launch_frow_n<S, RA, true>(epi, grid, st, data, ps, T, lm, ep);
+    else
+        launch_frow_n<S, RA, false>(epi, grid, st, data, ps, T, lm, ep);
 }
 template <int S, int RA>
 void launch_irow(dim3 grid, hipStream_t st, uint64_t *out, const uint64_t *in, size_t ps, const NttTables &T,
@@ -272,13 +284,13 @@ int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stri
     NttRange rr = r;
     rr.lm.polys = static_cast<uint32_t>(polys);
     if (phases & 1)
-    DISPATCH_S(ctx->plan.s1, 0, (launch_fcol<6, 3>(grid, st, data, poly_stride, T, rr.lm)),
-               (launch_fcol<7, 4>(grid, st, data, poly_stride, T, rr.lm)),
-               (launch_fcol<8, 4>(grid, st, data, poly_stride, T, rr.lm)));
+    DISPATCH_S(ctx->plan.s1, 0, (launch_fcol<6, 3>(ctx->narrow, grid, st, data, poly_stride, T, rr.lm)),
+               (launch_fcol<7, 4>(ctx->narrow, grid, st, data, poly_stride, T, rr.lm)),
+               (launch_fcol<8, 4>(ctx->narrow, grid, st, data, poly_stride, T, rr.lm)));
     if (phases & 2)
-    DISPATCH_S(ctx->plan.s2, 0, (launch_frow<6, 3>(epi, grid, st, data, poly_stride, T, rr.lm, ep)),
-               (launch_frow<7, 4>(epi, grid, st, data, poly_stride, T, rr.lm, ep)),
-               (launch_frow<8, 4>(epi, grid, st, data, poly_stride, T, rr.lm, ep)));
+    DISPATCH_S(ctx->plan.s2, 0, (launch_frow<6, 3>(ctx->narrow, epi, grid, st, data, poly_stride, T, rr.lm, ep)),
+               (launch_frow<7, 4>(ctx->narrow, epi, grid, st, data, poly_stride, T, rr.lm, ep)),
+               (launch_frow<8, 4>(ctx->narrow, epi, grid, st, data, poly_stride, T, rr.lm, ep)));
     return check_launch("forward NTT");
 }
 
@@ -594,6 +606,8 @@ int pha_context_create(int log_n, const uint64_t *moduli_QP, size_t size_QP, siz
     ctx->size_Q = size_QP - size_P;
     ctx->plan = plan;
     ctx->moduli.assign(moduli_QP, moduli_QP + size_QP);
+    ctx->narrow = true;
+    for (size_t i = 0; i < size_QP; i++) ctx->narrow = ctx->narrow && (moduli_QP[i] >> 60) == 0;
     ctx->host_tables.resize(size_QP);
     for (size_t i = 0; i < size_QP; i++) {
         for (size_t j = 0; j < i; j++)

@@ -230,3 +230,41 @@ def test_bad_chain_index(gpu, pha, small):
         ctx.modup(7, d, d)
     with pytest.raises(pha.PhantomError):
         ctx.rescale_to_next(6, d, 2, d)  # one limb left: end of chain
+
+
+def test_61_bit_modulus_uses_the_wide_path(gpu, pha, orc):
+    """Moduli may be 61 bits (MOD_BIT_COUNT_MAX, include/util/defines.h:4): then 16q overflows a word and
+    the kernels fall back to the [0,8q) lazy range.  Mixed chain: one 61-bit and one 60-bit prime."""
+    n = 4096
+    q61 = (1 << 61) - 2 * n + 1
+    while not orc.lib().orc_is_prime(q61):
+        q61 -= 2 * n
+    assert q61 >> 60 == 1
+    mods = np.array([q61, int(orc.coeff_modulus_create(n, [60])[0])], dtype=np.uint64)
+    ctx, o = pha.PhantomContext(12, mods, 0), orc.Oracle(12, mods, 0)
+    x = o.uniform_poly([0, 1], 321)
+    x[0, :4] = q61 - 1  # extreme residues
+    ref = x.copy()
+    o.nwt_forward_inplace(ref, 2, 0)
+    d = _dev(pha, x)
+    ctx.nwt_2d_radix8_forward_inplace(d, 2, 0)
+    assert (_host(pha, d) == ref).all()
+    ctx.nwt_2d_radix8_backward_inplace(d, 2, 0)
+    assert (_host(pha, d) == x).all()
+    ctx.close()
+
+
+def test_extreme_residues(gpu, pha, small):
+    """All coefficients q-1 (and 0): the lazy ranges are at their upper bounds in every stage."""
+    ctx, o = small
+    size = 8
+    tidx = list(range(8))
+    x = np.stack([np.full(4096, int(o.moduli[t]) - 1, dtype=np.uint64) for t in tidx])
+    x[:, ::7] = 0
+    ref = x.copy()
+    o.nwt_forward_inplace(ref, size, 0)
+    d = _dev(pha, x)
+    ctx.nwt_2d_radix8_forward_inplace(d, size, 0)
+    assert (_host(pha, d) == ref).all()
+    ctx.nwt_2d_radix8_backward_inplace(d, size, 0)
+    assert (_host(pha, d) == x).all()
