@@ -27,8 +27,10 @@ struct LimbMap {
     uint32_t size_QP, size_P;       // size_P > 0: last size_P limbs of the range use key-level table
                                     // indices size_QP - size_P + k (src/ntt/fntt_2d.cu:433-436)
     uint32_t excl_start, excl_end;  // limbs skipped (src/ntt/ntt_modup.cu:422); empty if start >= end
-    uint32_t active;                // limbs actually transformed = count - |excluded|
+    uint32_t active;                // limbs actually transformed = count - |excluded| (max over polys)
     uint32_t polys;                 // buffers [polys][...] handled by this launch
+    uint32_t digit_alpha;           // > 0: poly p is digit p of a modup buffer and skips its own limbs
+    uint32_t digit_limit;           //      [p*alpha, min((p+1)*alpha, digit_limit))  (src/rns_bconv.cu:616-620)
 };
 
 struct NttTables {
@@ -51,10 +53,19 @@ struct Epilogue {
 
 enum : int { EPI_NONE = 0, EPI_SUB_MUL = 1, EPI_SUB_MUL_ADD = 2, EPI_SCALE = 3 };
 
-__device__ __forceinline__ void resolve_limb(const LimbMap &m, uint32_t li, uint32_t &twr, uint32_t &tidx) {
+// returns false when this workgroup has nothing to do (ragged last digit)
+__device__ __forceinline__ bool resolve_limb(const LimbMap &m, uint32_t poly, uint32_t li, uint32_t &twr, uint32_t &tidx) {
+    uint32_t es = m.excl_start, ee = m.excl_end;
+    if (m.digit_alpha) {
+        es = poly * m.digit_alpha;
+        ee = min(es + m.digit_alpha, m.digit_limit);
+    }
+    const uint32_t len = ee > es ? ee - es : 0;
+    if (li >= m.count - len) return false;
     twr = m.start + li;
-    if (m.excl_end > m.excl_start && twr >= m.excl_start) twr += m.excl_end - m.excl_start;
+    if (len && twr >= es) twr += len;
     tidx = (m.size_P && twr >= m.start + m.count - m.size_P) ? m.size_QP - (m.start + m.count - twr) : twr;
+    return true;
 }
 
 // Work decomposition of a launch: one workgroup per (poly, limb, tile).  Workgroups b and b + 8
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void fntt_col_kernel(uint64_t *data, size
     decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
     const uint32_t li = tile / tiles, ti = tile % tiles;
     uint32_t twr, tidx;
-    resolve_limb(lm, li, twr, tidx);
+    if (!resolve_limb(lm, poly, li, twr, tidx)) return;
     uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + ti * C;
     const uint64_t q = T.mod[tidx].value;
     const LazyMod lmod(q);
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(kThreads) void fntt_row_kernel(uint64_t *data, size
     decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
     const uint32_t li = tile / tiles, ti = tile % tiles;
     uint32_t twr, tidx;
-    resolve_limb(lm, li, twr, tidx);
+    if (!resolve_limb(lm, poly, li, twr, tidx)) return;
     const size_t limb_off = static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
     uint64_t *base = data + poly * poly_stride + limb_off;
     const DModulus mod = T.mod[tidx];
@@ -290,7 +301,7 @@ __global__ __launch_bounds__(kThreads) void intt_row_kernel(uint64_t *out, const
     decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
     const uint32_t li = tile / tiles, ti = tile % tiles;
     uint32_t twr, tidx;
-    resolve_limb(lm, li, twr, tidx);
+    if (!resolve_limb(lm, poly, li, twr, tidx)) return;
     const size_t off = poly * poly_stride + static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
     const uint64_t *src = in + off;
     uint64_t *dst = out + off;
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(kThreads) void intt_col_kernel(uint64_t *data, size
     decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
     const uint32_t li = tile / tiles, ti = tile % tiles;
     uint32_t twr, tidx;
-    resolve_limb(lm, li, twr, tidx);
+    if (!resolve_limb(lm, poly, li, twr, tidx)) return;
     uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + ti * C;
     const uint64_t q = T.mod[tidx].value;
     const LazyMod lmod(q);

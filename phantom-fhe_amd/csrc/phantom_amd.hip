@@ -103,6 +103,9 @@ struct LevelTool {
     std::vector<DevBuf<uint32_t>> modup_obase_tidx;      // per digit: table index of each output limb
     DevBuf<uint64_t> moddown_matrix;
     DevBuf<uint32_t> moddown_obase_tidx;
+    bool uniform_digits = false;                         // alpha divides size_Ql: one launch for all digits
+    DevBuf<uint64_t> modup_matrix_all;
+    DevBuf<uint32_t> modup_tidx_all;
 };
 
 }  // namespace
@@ -222,7 +225,7 @@ int make_range(const pha_context *ctx, size_t count, size_t start, size_t size_Q
     r.active = static_cast<uint32_t>(count) - len;
     r.lm = LimbMap{static_cast<uint32_t>(start), static_cast<uint32_t>(count), static_cast<uint32_t>(size_QP),
                    static_cast<uint32_t>(size_P), static_cast<uint32_t>(excl_s), static_cast<uint32_t>(excl_e),
-                   r.active, 1u};
+                   r.active, 1u, 0u, 0u};
     return PHA_OK;
 }
 
@@ -345,6 +348,21 @@ int get_level(pha_context *ctx, size_t chain_index, LevelTool **out) {
         HIP_TRY(lt->modup_matrix[d].upload(lt->host.modup_matrix[d]));
         HIP_TRY(lt->modup_obase_tidx[d].upload(tidx));
     }
+    lt->uniform_digits = ctx->size_P > 1 && size_Ql % ctx->size_P == 0;
+    if (lt->uniform_digits) {
+        std::vector<uint64_t> mall;
+        std::vector<uint32_t> tall;
+        for (size_t d = 0; d < lt->beta; d++) {
+            const size_t s = d * ctx->size_P, e = s + ctx->size_P;
+            mall.insert(mall.end(), lt->host.modup_matrix[d].begin(), lt->host.modup_matrix[d].end());
+            for (size_t j = 0; j < size_Ql + ctx->size_P; j++) {
+                if (j >= s && j < e) continue;
+                tall.push_back(static_cast<uint32_t>(j < size_Ql ? j : ctx->size_Q + (j - size_Ql)));
+            }
+        }
+        HIP_TRY(lt->modup_matrix_all.upload(mall));
+        HIP_TRY(lt->modup_tidx_all.upload(tall));
+    }
     std::vector<uint32_t> tidx(size_Ql);
     for (size_t j = 0; j < size_Ql; j++) tidx[j] = static_cast<uint32_t>(j);
     HIP_TRY(lt->moddown_matrix.upload(lt->host.moddown_matrix));
@@ -355,16 +373,17 @@ int get_level(pha_context *ctx, size_t chain_index, LevelTool **out) {
 }
 
 int launch_bconv(pha_context *ctx, uint64_t *dst, const uint64_t *y, const uint64_t *matrix, const uint32_t *obase_tidx,
-                 uint32_t ibase, uint32_t obase, uint32_t skip_start, uint32_t skip_len, hipStream_t st) {
+                 uint32_t ibase, uint32_t obase, uint32_t skip_start, uint32_t skip_len, uint32_t batch,
+                 const BconvBatch &bt, hipStream_t st) {
     const uint32_t n = static_cast<uint32_t>(ctx->n);
     // enough workgroups to fill 256 CUs a few times over without re-reading the inputs too often
     uint32_t lpb = std::max<uint32_t>(1, obase / 8);
-    const dim3 grid(n / 256, (obase + lpb - 1) / lpb);
+    const dim3 grid(n / 256, (obase + lpb - 1) / lpb, batch);
     const DModulus *mod = ctx->d_mod.p;
 #define BCONV_CASE(IB)                                                                                          \
     case IB:                                                                                                    \
         hipLaunchKernelGGL((bconv_matmul_kernel<IB>), grid, dim3(256), 0, st, dst, y, matrix, mod, obase_tidx, \
-                           obase, lpb, n, skip_start, skip_len);                                               \
+                           obase, lpb, n, skip_start, skip_len, bt);                                           \
         break;
     switch (ibase) {
         BCONV_CASE(1) BCONV_CASE(2) BCONV_CASE(3) BCONV_CASE(4) BCONV_CASE(5) BCONV_CASE(6) BCONV_CASE(7) BCONV_CASE(8)
@@ -372,7 +391,7 @@ int launch_bconv(pha_context *ctx, uint64_t *dst, const uint64_t *y, const uint6
         BCONV_CASE(16)
         default:
             hipLaunchKernelGGL(bconv_matmul_generic_kernel, grid, dim3(256), 0, st, dst, y, matrix, mod, obase_tidx,
-                               ibase, obase, lpb, n, skip_start, skip_len);
+                               ibase, obase, lpb, n, skip_start, skip_len, bt);
     }
 #undef BCONV_CASE
     return check_launch("bconv_matmul");
@@ -394,21 +413,31 @@ int do_modup(pha_context *ctx, LevelTool *lt, uint64_t *dst, const uint64_t *cks
         ep.cst = lt->partHatInv.v.p;
         ep.cst_shoup = lt->partHatInv.s.p;
         PHA_TRY(ntt_backward(ctx, t_cks, cks, 1, 0, r, EPI_SCALE, ep, st));
-        for (size_t d = 0; d < lt->beta; d++) {
-            const size_t s = d * alpha, e = std::min(s + alpha, size_Ql), len = e - s;
-            uint64_t *part = dst + d * size_QlP * n;
-            HIP_TRY(hipMemcpyAsync(part + s * n, cks + s * n, len * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
-            PHA_TRY(launch_bconv(ctx, part, t_cks + s * n, lt->modup_matrix[d].p, lt->modup_obase_tidx[d].p,
-                                 static_cast<uint32_t>(len), static_cast<uint32_t>(size_QlP - len),
-                                 static_cast<uint32_t>(s), static_cast<uint32_t>(len), st));
+        if (lt->uniform_digits) {
+            const uint32_t obase = static_cast<uint32_t>(size_QlP - alpha);
+            BconvBatch bt{size_QlP * n, alpha * n, static_cast<size_t>(obase) * alpha, obase,
+                          static_cast<uint32_t>(alpha), cks, alpha * n};
+            PHA_TRY(launch_bconv(ctx, dst, t_cks, lt->modup_matrix_all.p, lt->modup_tidx_all.p,
+                                 static_cast<uint32_t>(alpha), obase, 0, static_cast<uint32_t>(alpha),
+                                 static_cast<uint32_t>(lt->beta), bt, st));
+        } else {
+            for (size_t d = 0; d < lt->beta; d++) {
+                const size_t s = d * alpha, e = std::min(s + alpha, size_Ql), len = e - s;
+                BconvBatch bt{0, 0, 0, 0, 0, cks + s * n, 0};
+                PHA_TRY(launch_bconv(ctx, dst + d * size_QlP * n, t_cks + s * n, lt->modup_matrix[d].p,
+                                     lt->modup_obase_tidx[d].p, static_cast<uint32_t>(len),
+                                     static_cast<uint32_t>(size_QlP - len), static_cast<uint32_t>(s),
+                                     static_cast<uint32_t>(len), 1, bt, st));
+            }
         }
     }
-    for (size_t d = 0; d < lt->beta; d++) {
-        const size_t s = d * alpha, e = std::min(s + alpha, size_Ql);
-        NttRange rr;
-        PHA_TRY(make_range(ctx, size_QlP, 0, ctx->size_QP, alpha, s, e, rr));
-        PHA_TRY(ntt_forward(ctx, dst + d * size_QlP * n, 1, 0, rr, EPI_NONE, Epilogue{}, st));
-    }
+    // one launch pair transforms every digit, each skipping its own (already NTT-form) limbs
+    NttRange rr;
+    PHA_TRY(make_range(ctx, size_QlP, 0, ctx->size_QP, alpha, 0, 0, rr));
+    rr.lm.digit_alpha = static_cast<uint32_t>(alpha);
+    rr.lm.digit_limit = static_cast<uint32_t>(size_Ql);
+    rr.active = rr.lm.active = static_cast<uint32_t>(size_QlP - std::min(alpha, size_Ql - (lt->beta - 1) * alpha));
+    PHA_TRY(ntt_forward(ctx, dst, lt->beta, size_QlP * n, rr, EPI_NONE, Epilogue{}, st));
     return PHA_OK;
 }
 
@@ -423,54 +452,56 @@ int do_inner_prod(pha_context *ctx, LevelTool *lt, uint64_t *cx, const uint64_t 
     return check_launch("key_switch_inner_prod");
 }
 
-// DRNSTool::moddown_from_NTT (src/rns_bconv.cu:776-828), delta = scratch [size_Ql][n].
-// addend != nullptr fuses add_to_ct: ct_i = addend + (cx - NTT(delta)) * PInv
-int do_moddown(pha_context *ctx, LevelTool *lt, uint64_t *ct_i, uint64_t *cx_i, uint64_t *delta,
-               const uint64_t *addend, hipStream_t st) {
-    const size_t n = ctx->n, size_Ql = lt->size_Ql, alpha = ctx->size_P;
+// DRNSTool::moddown_from_NTT (src/rns_bconv.cu:776-828) for `polys` buffers at once
+// (cx stride size_QlP*n, ct stride size_Ql*n), delta = scratch [polys][size_Ql][n].
+// addend != nullptr fuses add_to_ct: ct = addend + (cx - NTT(delta)) * PInv
+int do_moddown(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *cx, uint64_t *delta, const uint64_t *addend,
+               size_t polys, hipStream_t st) {
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, alpha = ctx->size_P, size_QlP = size_Ql + alpha;
     NttRange rp;
     PHA_TRY(make_range(ctx, alpha, size_Ql, ctx->size_QP, alpha, 0, 0, rp));
-    uint64_t *cp = cx_i + size_Ql * n;
+    uint64_t *cp = cx + size_Ql * n;
     if (alpha == 1) {
-        PHA_TRY(ntt_backward(ctx, cx_i, cx_i, 1, 0, rp, EPI_NONE, Epilogue{}, st));
-        hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(static_cast<uint32_t>(n / 512), 1), dim3(256), 0, st, delta,
-                           cp, ctx->d_mod.p, static_cast<uint32_t>(size_Ql), static_cast<uint32_t>(n), size_t(0),
-                           size_t(0));
+        PHA_TRY(ntt_backward(ctx, cx, cx, polys, size_QlP * n, rp, EPI_NONE, Epilogue{}, st));
+        hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(static_cast<uint32_t>(n / 512), static_cast<uint32_t>(polys)),
+                           dim3(256), 0, st, delta, cp, ctx->d_mod.p, static_cast<uint32_t>(size_Ql),
+                           static_cast<uint32_t>(n), size_Ql * n, size_QlP * n);
         PHA_TRY(check_launch("reduce_single_limb"));
     } else {
         // INTT fused with bconv phase 1 (x PHatInv mod p_k); constants indexed by buffer limb
         Epilogue ep{};
         ep.cst = lt->PHatInv.v.p - size_Ql;
         ep.cst_shoup = lt->PHatInv.s.p - size_Ql;
-        PHA_TRY(ntt_backward(ctx, cx_i, cx_i, 1, 0, rp, EPI_SCALE, ep, st));
+        PHA_TRY(ntt_backward(ctx, cx, cx, polys, size_QlP * n, rp, EPI_SCALE, ep, st));
+        BconvBatch bt{size_Ql * n, size_QlP * n, 0, 0, 0, nullptr, 0};
         PHA_TRY(launch_bconv(ctx, delta, cp, lt->moddown_matrix.p, lt->moddown_obase_tidx.p, static_cast<uint32_t>(alpha),
-                             static_cast<uint32_t>(size_Ql), static_cast<uint32_t>(size_Ql), 0, st));
+                             static_cast<uint32_t>(size_Ql), static_cast<uint32_t>(size_Ql), 0,
+                             static_cast<uint32_t>(polys), bt, st));
     }
     NttRange rq;
     PHA_TRY(make_range(ctx, size_Ql, 0, 0, 0, 0, 0, rq));
     Epilogue ep{};
-    ep.out = ct_i;
-    ep.sub = cx_i;
+    ep.out = ct;
+    ep.sub = cx;
     ep.addend = addend;
     ep.cst = lt->bigPInv.v.p;
     ep.cst_shoup = lt->bigPInv.s.p;
-    return ntt_forward(ctx, delta, 1, 0, rq, addend ? EPI_SUB_MUL_ADD : EPI_SUB_MUL, ep, st);
+    ep.out_poly_stride = size_Ql * n;
+    ep.sub_poly_stride = size_QlP * n;
+    return ntt_forward(ctx, delta, polys, size_Ql * n, rq, addend ? EPI_SUB_MUL_ADD : EPI_SUB_MUL, ep, st);
 }
 
 int do_keyswitch(pha_context *ctx, LevelTool *lt, uint64_t *ct, const uint64_t *c2, const uint64_t *const *evks,
                  hipStream_t st) {
     const size_t n = ctx->n, size_Ql = lt->size_Ql, size_QlP = size_Ql + ctx->size_P;
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + size_Ql) * n, &ws));
+    PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n, &ws));
     uint64_t *t_mod_up = ws, *cx = t_mod_up + lt->beta * size_QlP * n, *scratch = cx + 2 * size_QlP * n;
     PHA_TRY(do_modup(ctx, lt, t_mod_up, c2, scratch, st));
     PHA_TRY(do_inner_prod(ctx, lt, cx, t_mod_up, evks, st));
-    for (int i = 0; i < 2; i++) {
-        // moddown + add_to_ct fused into the NTT epilogue (src/eval_key_switch.cu:157-177)
-        uint64_t *ct_i = ct + i * size_Ql * n;
-        PHA_TRY(do_moddown(ctx, lt, ct_i, cx + i * size_QlP * n, scratch, ct_i, st));
-    }
-    return PHA_OK;
+    // both polys' moddown in one launch sequence, add_to_ct fused into the NTT epilogue
+    // (src/eval_key_switch.cu:157-177)
+    return do_moddown(ctx, lt, ct, cx, scratch, ct, 2, st);
 }
 
 int do_rescale(pha_context *ctx, LevelTool *lt, const uint64_t *src, const uint64_t *last_coeff, size_t last_stride,
@@ -779,7 +810,7 @@ int pha_moddown_from_ntt(pha_context *ctx, size_t chain_index, uint64_t *ct_i, u
     PHA_TRY(get_level(ctx, chain_index, &lt));
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, lt->size_Ql * ctx->n, &ws));
-    return do_moddown(ctx, lt, ct_i, cx_i, ws, nullptr, as_stream(stream));
+    return do_moddown(ctx, lt, ct_i, cx_i, ws, nullptr, 1, as_stream(stream));
 }
 
 int pha_add_to_ct(pha_context *ctx, uint64_t *ct, const uint64_t *cx, size_t size_Ql, pha_stream_t stream) {
@@ -876,7 +907,7 @@ int pha_apply_galois_inplace(pha_context *ctx, size_t chain_index, uint64_t *ct,
     const size_t n = ctx->n, size_Ql = lt->size_Ql, size_QlP = size_Ql + ctx->size_P;
     hipStream_t st = as_stream(stream);
     // workspace: [key-switch scratch][temp for both permuted polys]
-    const size_t ks_words = (lt->beta * size_QlP + 2 * size_QlP + size_Ql) * n;
+    const size_t ks_words = (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n;
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, ks_words + 2 * size_Ql * n, &ws));
     uint64_t *temp = ws + ks_words;

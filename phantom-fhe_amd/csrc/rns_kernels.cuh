@@ -14,15 +14,35 @@ namespace pha {
 // One lane owns one coefficient: its IB inputs stay in registers and are reused for every
 // output limb of the block's limb group; the matrix row is wave-uniform (scalar loads).
 // ---------------------------------------------------------------------------------------------
+// blockIdx.z batches independent conversions that share the shape (the beta digits of modup when
+// alpha divides size_Ql, or the two polys of moddown): every pointer advances by its z-stride.
+struct BconvBatch {
+    size_t dst_stride, y_stride, matrix_stride, tidx_stride;
+    uint32_t skip_stride;
+    const uint64_t *copy_src;  // optional: the digit's own (NTT-form) limbs, copied to the skipped slots
+    size_t copy_stride;        // (src/rns_bconv.cu:522-528 modup_copy_partQl_kernel, fused)
+};
+
 template <int IB>
 __global__ __launch_bounds__(256) void bconv_matmul_kernel(uint64_t *dst, const uint64_t *y, const uint64_t *matrix,
                                                            const DModulus *obase_mod, const uint32_t *obase_tidx,
                                                            uint32_t obase_size, uint32_t limbs_per_block, uint32_t n,
-                                                           uint32_t skip_start, uint32_t skip_len) {
+                                                           uint32_t skip_start, uint32_t skip_len, BconvBatch bt) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t z = blockIdx.z;
+    dst += z * bt.dst_stride;
+    y += z * bt.y_stride;
+    matrix += z * bt.matrix_stride;
+    obase_tidx += z * bt.tidx_stride;
+    skip_start += z * bt.skip_stride;
     uint64_t in[IB];
 #pragma unroll
     for (int i = 0; i < IB; i++) in[i] = y[static_cast<size_t>(i) * n + k];
+    if (bt.copy_src != nullptr && blockIdx.y == 0) {
+        const uint64_t *src = bt.copy_src + z * bt.copy_stride;
+#pragma unroll
+        for (int i = 0; i < IB; i++) dst[static_cast<size_t>(skip_start + i) * n + k] = src[static_cast<size_t>(i) * n + k];
+    }
     const uint32_t j0 = blockIdx.y * limbs_per_block;
     const uint32_t j1 = min(j0 + limbs_per_block, obase_size);
     for (uint32_t j = j0; j < j1; j++) {
@@ -41,8 +61,20 @@ __global__ __launch_bounds__(256) void bconv_matmul_generic_kernel(uint64_t *dst
                                                                    const uint64_t *matrix, const DModulus *obase_mod,
                                                                    const uint32_t *obase_tidx, uint32_t ibase_size,
                                                                    uint32_t obase_size, uint32_t limbs_per_block,
-                                                                   uint32_t n, uint32_t skip_start, uint32_t skip_len) {
+                                                                   uint32_t n, uint32_t skip_start, uint32_t skip_len,
+                                                                   BconvBatch bt) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t z = blockIdx.z;
+    dst += z * bt.dst_stride;
+    y += z * bt.y_stride;
+    matrix += z * bt.matrix_stride;
+    obase_tidx += z * bt.tidx_stride;
+    skip_start += z * bt.skip_stride;
+    if (bt.copy_src != nullptr && blockIdx.y == 0) {
+        const uint64_t *src = bt.copy_src + z * bt.copy_stride;
+        for (uint32_t i = 0; i < ibase_size; i++)
+            dst[static_cast<size_t>(skip_start + i) * n + k] = src[static_cast<size_t>(i) * n + k];
+    }
     const uint32_t j0 = blockIdx.y * limbs_per_block;
     const uint32_t j1 = min(j0 + limbs_per_block, obase_size);
     for (uint32_t j = j0; j < j1; j++) {
