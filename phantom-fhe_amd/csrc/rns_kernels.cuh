@@ -23,9 +23,38 @@ struct BconvBatch {
     size_t copy_stride;        // (src/rns_bconv.cu:522-528 modup_copy_partQl_kernel, fused)
 };
 
+// 128-bit dot product by columns: every input and matrix entry is a residue < 2^61, so the high
+// words are < 2^29.  c0 collects the low x low products with an explicit carry counter (the
+// carry-out of v_mad_u64_u32 feeds a v_addc); the cross terms (< 2^61 each) go to accumulators
+// that take at most 8 terms, the high x high products (< 2^58) never overflow.  4 multiplies and
+// one add-with-carry per term instead of a full 128-bit add.
 template <int IB>
-__global__ __launch_bounds__(256) void bconv_matmul_kernel(uint64_t *dst, const uint64_t *y, const uint64_t *matrix,
-                                                           const DModulus *obase_mod, const uint32_t *obase_tidx,
+__device__ __forceinline__ u128_t dot_residues(const uint64_t (&in)[IB], const uint64_t *__restrict__ row) {
+    static_assert(IB <= 16, "cross-term accumulators hold 8 terms each");
+    uint64_t c0 = 0, c2 = 0, c1[4] = {0, 0, 0, 0};
+    uint32_t k0 = 0;
+#pragma unroll
+    for (int i = 0; i < IB; i++) {
+        const uint32_t x0 = lo32(in[i]), x1 = hi32(in[i]), m0 = lo32(row[i]), m1 = hi32(row[i]);
+        asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "+v"(c0), "+v"(k0)
+            : "v"(x0), "s"(m0)
+            : "vcc");
+        c1[(i >> 3) * 2] = mad32(x0, m1, c1[(i >> 3) * 2]);
+        c1[(i >> 3) * 2 + 1] = mad32(x1, m0, c1[(i >> 3) * 2 + 1]);
+        c2 = mad32(x1, m1, c2);
+    }
+    unsigned __int128 acc = static_cast<unsigned __int128>(c0) + (static_cast<unsigned __int128>(c2 + k0) << 64);
+#pragma unroll
+    for (int t = 0; t < (IB > 8 ? 4 : 2); t++) acc += static_cast<unsigned __int128>(c1[t]) << 32;
+    return u128_t{static_cast<uint64_t>(acc), static_cast<uint64_t>(acc >> 64)};
+}
+
+template <int IB>
+__global__ __launch_bounds__(256) void bconv_matmul_kernel(uint64_t *__restrict__ dst, const uint64_t *__restrict__ y,
+                                                           const uint64_t *__restrict__ matrix,
+                                                           const DModulus *__restrict__ obase_mod,
+                                                           const uint32_t *__restrict__ obase_tidx,
                                                            uint32_t obase_size, uint32_t limbs_per_block, uint32_t n,
                                                            uint32_t skip_start, uint32_t skip_len, BconvBatch bt) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
@@ -46,10 +75,7 @@ __global__ __launch_bounds__(256) void bconv_matmul_kernel(uint64_t *dst, const 
     const uint32_t j0 = blockIdx.y * limbs_per_block;
     const uint32_t j1 = min(j0 + limbs_per_block, obase_size);
     for (uint32_t j = j0; j < j1; j++) {
-        const uint64_t *row = matrix + static_cast<size_t>(j) * IB;
-        u128_t acc = mul64x64(in[0], row[0]);
-#pragma unroll
-        for (int i = 1; i < IB; i++) add128(acc, mul64x64(in[i], row[i]));
+        const u128_t acc = dot_residues<IB>(in, matrix + static_cast<size_t>(j) * IB);
         const DModulus m = obase_mod[obase_tidx[j]];
         const uint32_t jo = j + (j >= skip_start ? skip_len : 0);
         dst[static_cast<size_t>(jo) * n + k] = barrett128(acc, m);

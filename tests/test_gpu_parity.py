@@ -268,3 +268,27 @@ def test_extreme_residues(gpu, pha, small):
     assert (_host(pha, d) == ref).all()
     ctx.nwt_2d_radix8_backward_inplace(d, size, 0)
     assert (_host(pha, d) == x).all()
+
+
+@pytest.mark.parametrize("size_p", [2, 3])
+def test_keyswitch_60bit_primes_extreme_residues(gpu, pha, orc, size_p):
+    """All primes 60 bits, inputs q-1 everywhere: the 128-bit column accumulators of the base
+    conversion and the inner product see their largest carries."""
+    mods = orc.coeff_modulus_create(4096, [60] * (6 + size_p))
+    ctx, o = pha.PhantomContext(12, mods, size_p), orc.Oracle(12, mods, size_p)
+    size_ql = 6
+    evk_h = [np.ascontiguousarray(np.stack([np.stack([np.full(4096, int(m) - 1, dtype=np.uint64) for m in mods])] * 2))
+             for _ in range(o.size_Q // size_p)]
+    evk_d = pha.EvalKey([pha.to_device(h) for h in evk_h])
+    c2 = np.stack([np.full(4096, int(m) - 1, dtype=np.uint64) for m in mods[:size_ql]])
+    ct = np.stack([c2, c2])
+    ref = ct.copy()
+    o.keyswitch_inplace(size_ql, ref, c2, evk_h)
+    d = _dev(pha, ct)
+    ctx.keyswitch_inplace(1, d, _dev(pha, c2), evk_d)
+    assert (_host(pha, d) == ref).all()
+    t_ref = o.modup(size_ql, c2)
+    d_t = _dev(pha, np.zeros_like(t_ref))
+    ctx.modup(1, d_t, _dev(pha, c2))
+    assert (_host(pha, d_t) == t_ref).all()
+    ctx.close()
