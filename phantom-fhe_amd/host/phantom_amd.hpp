@@ -1,0 +1,346 @@
+// C++ host layer over the C ABI (include/phantom_amd.h): the evaluator-facing objects and entry
+// points of the reference, re-created natively for HIP.  Names, argument meaning and error
+// behaviour follow include/evaluate.cuh, include/context.cuh, include/ciphertext.h and
+// include/secretkey.h of the reference (cited per item); nothing here computes on the CPU — every
+// operation is a call into libphantom_amd.so on the given HIP stream.
+//
+// Header-only; compile with hipcc (or any C++17 compiler plus the HIP runtime headers) and link
+// -lphantom_amd -lamdhip64.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/phantom_amd.h"
+
+namespace phantom {
+
+// ---- error mapping: C status codes back to the exceptions the reference throws -----------------
+inline void check(int rc) {
+    if (rc == PHA_OK) return;
+    const std::string msg = pha_last_error();
+    if (rc == PHA_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
+    if (rc == PHA_ERR_LOGIC) throw std::logic_error(msg);
+    throw std::runtime_error(msg);  // HIP failure (the reference prints and exits, include/cuda_wrapper.cuh:19-43)
+}
+inline void check_hip(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// ---- stream + device memory (include/cuda_wrapper.cuh:47-186) ----------------------------------
+class hip_stream_wrapper {
+    hipStream_t stream_ = nullptr;
+
+public:
+    hip_stream_wrapper() { check_hip(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate"); }
+    ~hip_stream_wrapper() {
+        if (stream_) (void)hipStreamDestroy(stream_);
+    }
+    hip_stream_wrapper(const hip_stream_wrapper &) = delete;
+    hip_stream_wrapper &operator=(const hip_stream_wrapper &) = delete;
+    const hipStream_t &get_stream() const { return stream_; }
+};
+
+// RAII device buffer of uint64_t words
+class device_words {
+    uint64_t *p_ = nullptr;
+    size_t n_ = 0;
+
+public:
+    device_words() = default;
+    explicit device_words(size_t n) { reset(n); }
+    ~device_words() { release(); }
+    device_words(const device_words &) = delete;
+    device_words &operator=(const device_words &) = delete;
+    device_words(device_words &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr, o.n_ = 0; }
+    device_words &operator=(device_words &&o) noexcept {
+        if (this != &o) {
+            release();
+            p_ = o.p_, n_ = o.n_;
+            o.p_ = nullptr, o.n_ = 0;
+        }
+        return *this;
+    }
+    void release() {
+        if (p_) (void)hipFree(p_);
+        p_ = nullptr, n_ = 0;
+    }
+    void reset(size_t n) {
+        release();
+        if (n) check_hip(hipMalloc(reinterpret_cast<void **>(&p_), n * sizeof(uint64_t)), "hipMalloc");
+        n_ = n;
+    }
+    uint64_t *get() const { return p_; }
+    size_t size() const { return n_; }
+};
+
+// ---- parameters (include/util/encryptionparams.h:68-207, CKKS subset) ---------------------------
+namespace arith {
+struct CoeffModulus {
+    // src/modulus.cu:79-110
+    static std::vector<uint64_t> Create(size_t poly_modulus_degree, const std::vector<int> &bit_sizes) {
+        std::vector<uint64_t> out(bit_sizes.size());
+        check(pha_coeff_modulus_create(poly_modulus_degree, bit_sizes.data(), bit_sizes.size(), out.data()));
+        return out;
+    }
+};
+}  // namespace arith
+
+class EncryptionParameters {
+    size_t poly_modulus_degree_ = 0;
+    std::vector<uint64_t> coeff_modulus_;
+    size_t special_modulus_size_ = 1;  // include/util/encryptionparams.h:375
+
+public:
+    void set_poly_modulus_degree(size_t n) { poly_modulus_degree_ = n; }
+    void set_coeff_modulus(const std::vector<uint64_t> &m) { coeff_modulus_ = m; }
+    void set_special_modulus_size(size_t s) { special_modulus_size_ = s; }
+    size_t poly_modulus_degree() const { return poly_modulus_degree_; }
+    const std::vector<uint64_t> &coeff_modulus() const { return coeff_modulus_; }
+    size_t special_modulus_size() const { return special_modulus_size_; }
+};
+
+// ---- context (include/context.cuh, src/context.cu:120-290) --------------------------------------
+// chain index 0 = key level (Q ∪ P), 1 = first data level (Q), k = Q minus its last k-1 primes
+class PhantomContext {
+    pha_context *h_ = nullptr;
+    EncryptionParameters parms_;
+    size_t size_Q_ = 0;
+    int log_n_ = 0;
+
+public:
+    explicit PhantomContext(const EncryptionParameters &parms) : parms_(parms) {
+        const size_t n = parms.poly_modulus_degree();
+        if (n == 0 || (n & (n - 1))) throw std::invalid_argument("poly_modulus_degree is invalid");
+        while ((size_t(1) << log_n_) < n) ++log_n_;
+        const auto &m = parms.coeff_modulus();
+        if (parms.special_modulus_size() >= m.size()) throw std::invalid_argument("coeff_modulus is invalid");
+        size_Q_ = m.size() - parms.special_modulus_size();
+        check(pha_context_create(log_n_, m.data(), m.size(), parms.special_modulus_size(), &h_));
+    }
+    ~PhantomContext() { pha_context_destroy(h_); }
+    PhantomContext(const PhantomContext &) = delete;
+    PhantomContext &operator=(const PhantomContext &) = delete;
+
+    pha_context *handle() const { return h_; }
+    const EncryptionParameters &key_parms() const { return parms_; }
+    size_t poly_degree() const { return parms_.poly_modulus_degree(); }
+    int log_n() const { return log_n_; }
+    size_t size_Q() const { return size_Q_; }
+    size_t size_P() const { return parms_.special_modulus_size(); }
+    size_t get_first_index() const { return 1; }
+    size_t get_next_index(size_t chain_index) const { return chain_index + 1; }
+    // number of limbs of a ciphertext at chain_index (context.cu:148-174)
+    size_t coeff_mod_size(size_t chain_index) const {
+        if (chain_index < 1 || chain_index > size_Q_) throw std::invalid_argument("chain_index out of range");
+        return size_Q_ - (chain_index - 1);
+    }
+    uint64_t modulus(size_t i) const { return parms_.coeff_modulus().at(i); }
+};
+
+// ---- ciphertext container (include/ciphertext.h:6-262) ------------------------------------------
+class PhantomCiphertext {
+    size_t size_ = 0, coeff_modulus_size_ = 0, poly_modulus_degree_ = 0, chain_index_ = 0;
+    double scale_ = 1.0;
+    bool is_ntt_form_ = true;
+    device_words data_;
+
+public:
+    PhantomCiphertext() = default;
+    PhantomCiphertext(PhantomCiphertext &&) = default;
+    PhantomCiphertext &operator=(PhantomCiphertext &&) = default;
+
+    // reallocates and keeps the overlapping prefix, like ciphertext.h:56-86
+    void resize(const PhantomContext &context, size_t chain_index, size_t size, const hipStream_t &stream) {
+        const size_t limbs = context.coeff_mod_size(chain_index), n = context.poly_degree();
+        resize(size, limbs, n, stream);
+        chain_index_ = chain_index;
+    }
+    void resize(size_t size, size_t coeff_modulus_size, size_t poly_modulus_degree, const hipStream_t &stream) {
+        const size_t words = size * coeff_modulus_size * poly_modulus_degree;
+        if (words != data_.size()) {
+            device_words fresh(words);
+            const size_t keep = std::min(words, data_.size());
+            if (keep)
+                check_hip(hipMemcpyAsync(fresh.get(), data_.get(), keep * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream),
+                          "hipMemcpyAsync");
+            if (words > keep)
+                check_hip(hipMemsetAsync(fresh.get() + keep, 0, (words - keep) * sizeof(uint64_t), stream), "hipMemsetAsync");
+            check_hip(hipStreamSynchronize(stream), "hipStreamSynchronize");  // old buffer is freed below
+            data_ = std::move(fresh);
+        }
+        size_ = size, coeff_modulus_size_ = coeff_modulus_size, poly_modulus_degree_ = poly_modulus_degree;
+    }
+    uint64_t *data() const { return data_.get(); }
+    size_t size() const { return size_; }
+    size_t coeff_modulus_size() const { return coeff_modulus_size_; }
+    size_t poly_modulus_degree() const { return poly_modulus_degree_; }
+    size_t chain_index() const { return chain_index_; }
+    double scale() const { return scale_; }
+    bool is_ntt_form() const { return is_ntt_form_; }
+    void set_scale(double s) { scale_ = s; }
+    void set_ntt_form(bool b) { is_ntt_form_ = b; }
+    void set_chain_index(size_t c) { chain_index_ = c; }
+};
+
+// ---- switching keys (include/secretkey.h:85-113): dnum buffers [2][size_QP][N] + pointer array ----
+class PhantomRelinKey {
+    std::vector<device_words> digits_;
+    device_words ptrs_;
+
+public:
+    PhantomRelinKey() = default;
+    // takes ownership of already-generated key material (key generation is outside this layer)
+    explicit PhantomRelinKey(std::vector<device_words> &&digits) : digits_(std::move(digits)), ptrs_(digits_.size()) {
+        std::vector<uint64_t> h(digits_.size());
+        for (size_t i = 0; i < h.size(); i++) h[i] = reinterpret_cast<uint64_t>(digits_[i].get());
+        check_hip(hipMemcpy(ptrs_.get(), h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice), "hipMemcpy");
+    }
+    const uint64_t *const *public_keys_ptr() const { return reinterpret_cast<const uint64_t *const *>(ptrs_.get()); }
+    size_t dnum() const { return digits_.size(); }
+};
+
+class PhantomGaloisKey {
+    std::map<uint32_t, PhantomRelinKey> keys_;
+
+public:
+    void insert(uint32_t galois_elt, PhantomRelinKey &&key) { keys_[galois_elt] = std::move(key); }
+    bool has(uint32_t galois_elt) const { return keys_.count(galois_elt) != 0; }
+    const PhantomRelinKey &get_relin_keys(uint32_t galois_elt) const {
+        auto it = keys_.find(galois_elt);
+        if (it == keys_.end()) throw std::invalid_argument("Galois elt not present");
+        return it->second;
+    }
+};
+
+// ---- L4 free functions (include/ntt.cuh:47-94) ---------------------------------------------------
+inline void nwt_2d_radix8_forward_inplace(uint64_t *inout, const PhantomContext &c, size_t coeff_modulus_size,
+                                          size_t start_modulus_idx, const hipStream_t &s) {
+    check(pha_nwt_2d_radix8_forward_inplace(c.handle(), inout, coeff_modulus_size, start_modulus_idx, s));
+}
+inline void nwt_2d_radix8_backward_inplace(uint64_t *inout, const PhantomContext &c, size_t coeff_modulus_size,
+                                           size_t start_modulus_idx, const hipStream_t &s) {
+    check(pha_nwt_2d_radix8_backward_inplace(c.handle(), inout, coeff_modulus_size, start_modulus_idx, s));
+}
+inline void nwt_2d_radix8_backward(uint64_t *out, const uint64_t *in, const PhantomContext &c, size_t coeff_modulus_size,
+                                   size_t start_modulus_idx, const hipStream_t &s) {
+    check(pha_nwt_2d_radix8_backward(c.handle(), out, in, coeff_modulus_size, start_modulus_idx, s));
+}
+// src/eval_key_switch.cu:91-178
+inline void keyswitch_inplace(const PhantomContext &c, PhantomCiphertext &encrypted, uint64_t *c2,
+                              const PhantomRelinKey &relin_keys, bool /*is_relin*/, const hipStream_t &s) {
+    check(pha_keyswitch_inplace(c.handle(), encrypted.chain_index(), encrypted.data(), c2, relin_keys.public_keys_ptr(), s));
+}
+
+// ---- evaluator entry points (include/evaluate.cuh:114-294) ---------------------------------------
+// src/evaluate.cu:229-280,387-440
+inline void multiply_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2,
+                             const hip_stream_wrapper &stream_wrapper) {
+    if (!(encrypted1.is_ntt_form() && encrypted2.is_ntt_form()))
+        throw std::invalid_argument("encrypted1 and encrypted2 must be in NTT form");
+    if (encrypted1.chain_index() != encrypted2.chain_index())
+        throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+    if (encrypted1.size() != 2 || encrypted2.size() != 2)
+        throw std::invalid_argument("only size-2 ciphertexts are supported by this layer");  // mxn tensor: not on the hot path
+    const hipStream_t &s = stream_wrapper.get_stream();
+    const size_t limbs = context.coeff_mod_size(encrypted1.chain_index());
+    const bool square = &encrypted1 == &encrypted2;
+    encrypted1.resize(context, encrypted1.chain_index(), 3, s);
+    if (square)
+        check(pha_tensor_square_2x2(context.handle(), encrypted1.data(), limbs, encrypted1.data(), s));
+    else
+        check(pha_tensor_prod_2x2(context.handle(), encrypted1.data(), encrypted2.data(), limbs, encrypted1.data(), s));
+    encrypted1.set_scale(encrypted1.scale() * encrypted2.scale());
+}
+
+// src/evaluate.cu:553-583
+inline void relinearize_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, const PhantomRelinKey &relin_keys,
+                                const hip_stream_wrapper &stream_wrapper) {
+    if (encrypted.size() != 3) throw std::invalid_argument("destination_size must be 3");
+    if (!encrypted.is_ntt_form()) throw std::invalid_argument("CKKS encrypted must be in NTT form");
+    const hipStream_t &s = stream_wrapper.get_stream();
+    const size_t limbs = context.coeff_mod_size(encrypted.chain_index()), n = context.poly_degree();
+    keyswitch_inplace(context, encrypted, encrypted.data() + 2 * limbs * n, relin_keys, true, s);
+    encrypted.resize(2, limbs, n, s);
+}
+
+inline void multiply_and_relin_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1,
+                                       const PhantomCiphertext &encrypted2, const PhantomRelinKey &relin_keys,
+                                       const hip_stream_wrapper &stream_wrapper) {
+    multiply_inplace(context, encrypted1, encrypted2, stream_wrapper);
+    relinearize_inplace(context, encrypted1, relin_keys, stream_wrapper);
+}
+
+// src/evaluate.cu:585-616,725-745
+inline PhantomCiphertext rescale_to_next(const PhantomContext &context, const PhantomCiphertext &encrypted,
+                                         const hip_stream_wrapper &stream_wrapper) {
+    if (encrypted.chain_index() == context.size_Q()) throw std::invalid_argument("end of modulus switching chain reached");
+    const hipStream_t &s = stream_wrapper.get_stream();
+    PhantomCiphertext destination;
+    destination.resize(context, context.get_next_index(encrypted.chain_index()), encrypted.size(), s);
+    check(pha_rescale_to_next(context.handle(), encrypted.chain_index(), encrypted.data(), encrypted.size(),
+                              destination.data(), s));
+    destination.set_ntt_form(encrypted.is_ntt_form());
+    const size_t last = context.coeff_mod_size(encrypted.chain_index()) - 1;
+    destination.set_scale(encrypted.scale() / static_cast<double>(context.modulus(last)));
+    return destination;
+}
+inline void rescale_to_next_inplace(const PhantomContext &context, PhantomCiphertext &encrypted,
+                                    const hip_stream_wrapper &stream_wrapper) {
+    encrypted = rescale_to_next(context, encrypted, stream_wrapper);
+}
+
+// src/evaluate.cu:747-794
+inline void apply_galois_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, uint32_t galois_elt,
+                                 const PhantomGaloisKey &galois_keys, const hip_stream_wrapper &stream_wrapper) {
+    if (encrypted.size() > 2) throw std::invalid_argument("encrypted size must be 2");
+    const PhantomRelinKey &key = galois_keys.get_relin_keys(galois_elt);
+    check(pha_apply_galois_inplace(context.handle(), encrypted.chain_index(), encrypted.data(), galois_elt,
+                                   key.public_keys_ptr(), stream_wrapper.get_stream()));
+}
+
+// non-adjacent form of a rotation step (the reference falls back to it when no key exists for
+// the step itself, src/evaluate.cu:821-839)
+inline std::vector<int> naf(int value) {
+    std::vector<int> res;
+    const bool neg = value < 0;
+    unsigned v = static_cast<unsigned>(std::abs(value));
+    for (int bit = 0; v; ++bit) {
+        int d = 0;
+        if (v & 1) {
+            d = 2 - static_cast<int>(v & 3);  // +1 or -1
+            v = static_cast<unsigned>(static_cast<int>(v) - d);
+        }
+        if (d) res.push_back((neg ? -d : d) * (1 << bit));
+        v >>= 1;
+    }
+    return res;
+}
+
+// src/evaluate.cu:797-852
+inline void rotate_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, int step,
+                           const PhantomGaloisKey &galois_key, const hip_stream_wrapper &stream_wrapper) {
+    if (step == 0) return;
+    uint32_t elt = 0;
+    check(pha_galois_elt_from_step(context.log_n(), step, &elt));
+    if (galois_key.has(elt)) {
+        apply_galois_inplace(context, encrypted, elt, galois_key, stream_wrapper);
+        return;
+    }
+    const std::vector<int> parts = naf(step);
+    if (parts.size() == 1) throw std::invalid_argument("Galois key not present");
+    for (int part : parts) {
+        if (static_cast<size_t>(std::abs(part)) != (context.poly_degree() >> 1))
+            rotate_inplace(context, encrypted, part, galois_key, stream_wrapper);
+    }
+}
+
+}  // namespace phantom

@@ -1,0 +1,135 @@
+// Drives the C++ host layer (phantom-fhe_amd/host/phantom_amd.hpp) the way the reference's tests
+// drive evaluate.cuh (tests/relin.cu, tests/rotation.cu, tests/rescale_to_next.cu): build
+// parameters, context and keys, run an evaluator entry point, report the result.  Inputs are the
+// seeded uniform residues of the oracle (SplitMix64 + rejection), the results are printed as
+// FNV-1a digests and compared with the oracle by tests/test_cpp_host.py.
+#include <cstdio>
+#include <cstring>
+
+#include "../../phantom-fhe_amd/host/phantom_amd.hpp"
+
+using namespace phantom;
+
+static uint64_t splitmix64(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static void fill_uniform(uint64_t *out, size_t count, uint64_t q, uint64_t seed) {
+    uint64_t s = seed;
+    const int bits = 64 - __builtin_clzll(q);
+    const uint64_t mask = bits >= 64 ? ~0ULL : ((1ULL << bits) - 1);
+    for (size_t i = 0; i < count; i++) {
+        uint64_t v;
+        do v = splitmix64(s) & mask; while (v >= q);
+        out[i] = v;
+    }
+}
+// [limbs][n], limb i modulo moduli[idx0 + i], seeded like oracle.Oracle.uniform_poly
+static std::vector<uint64_t> uniform_poly(const std::vector<uint64_t> &moduli, size_t idx0, size_t limbs, size_t n, uint64_t seed) {
+    std::vector<uint64_t> v(limbs * n);
+    for (size_t i = 0; i < limbs; i++) fill_uniform(v.data() + i * n, n, moduli[idx0 + i], seed * 1000003ULL + i);
+    return v;
+}
+static uint64_t fnv(const std::vector<uint64_t> &v) {
+    uint64_t h = 0xcbf29ce484222325ULL;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(v.data());
+    for (size_t i = 0; i < v.size() * 8; i++) h = (h ^ p[i]) * 0x100000001b3ULL;
+    return h;
+}
+static std::vector<uint64_t> download(const PhantomCiphertext &ct) {
+    std::vector<uint64_t> h(ct.size() * ct.coeff_modulus_size() * ct.poly_modulus_degree());
+    check_hip(hipDeviceSynchronize(), "sync");
+    check_hip(hipMemcpy(h.data(), ct.data(), h.size() * 8, hipMemcpyDeviceToHost), "download");
+    return h;
+}
+static PhantomCiphertext make_ct(const PhantomContext &ctx, const std::vector<uint64_t> &moduli, size_t chain, uint64_t seed0,
+                                 uint64_t seed1, const hipStream_t &s) {
+    PhantomCiphertext ct;
+    ct.resize(ctx, chain, 2, s);
+    const size_t limbs = ctx.coeff_mod_size(chain), n = ctx.poly_degree();
+    auto a = uniform_poly(moduli, 0, limbs, n, seed0), b = uniform_poly(moduli, 0, limbs, n, seed1);
+    check_hip(hipMemcpy(ct.data(), a.data(), a.size() * 8, hipMemcpyHostToDevice), "upload");
+    check_hip(hipMemcpy(ct.data() + limbs * n, b.data(), b.size() * 8, hipMemcpyHostToDevice), "upload");
+    ct.set_scale(1099511627776.0);
+    return ct;
+}
+static PhantomRelinKey make_key(const std::vector<uint64_t> &moduli, size_t size_P, size_t n, uint64_t seed) {
+    const size_t size_QP = moduli.size(), dnum = (size_QP - size_P) / size_P;
+    std::vector<device_words> digits;
+    for (size_t d = 0; d < dnum; d++) {
+        auto b = uniform_poly(moduli, 0, size_QP, n, seed + 10 * d), a = uniform_poly(moduli, 0, size_QP, n, seed + 10 * d + 1);
+        device_words w(2 * size_QP * n);
+        check_hip(hipMemcpy(w.get(), b.data(), b.size() * 8, hipMemcpyHostToDevice), "upload");
+        check_hip(hipMemcpy(w.get() + size_QP * n, a.data(), a.size() * 8, hipMemcpyHostToDevice), "upload");
+        digits.push_back(std::move(w));
+    }
+    return PhantomRelinKey(std::move(digits));
+}
+
+int main() {
+    try {
+        const size_t n = 4096, size_P = 2;
+        EncryptionParameters parms;
+        parms.set_poly_modulus_degree(n);
+        parms.set_coeff_modulus(arith::CoeffModulus::Create(n, {45, 45, 45, 45, 55, 55}));
+        parms.set_special_modulus_size(size_P);
+        PhantomContext context(parms);
+        const auto &moduli = parms.coeff_modulus();
+        hip_stream_wrapper sw;
+        const hipStream_t &s = sw.get_stream();
+
+        PhantomRelinKey rlk = make_key(moduli, size_P, n, 70);
+        PhantomGaloisKey gk;
+        uint32_t e1, e4, em1;
+        check(pha_galois_elt_from_step(12, 1, &e1));
+        check(pha_galois_elt_from_step(12, 4, &e4));
+        check(pha_galois_elt_from_step(12, -1, &em1));
+        gk.insert(e1, make_key(moduli, size_P, n, 170));
+        gk.insert(e4, make_key(moduli, size_P, n, 270));
+        gk.insert(em1, make_key(moduli, size_P, n, 370));
+        printf("{\"galois_elts\": [%u, %u, %u]}\n", e1, e4, em1);
+
+        // HMult + relinearize + rescale (tests/relin.cu, tests/rescale_to_next.cu)
+        PhantomCiphertext x = make_ct(context, moduli, 1, 7, 8, s), y = make_ct(context, moduli, 1, 17, 18, s);
+        multiply_and_relin_inplace(context, x, y, rlk, sw);
+        printf("{\"multiply_relin\": \"%016llx\", \"size\": %zu, \"scale\": %.1f}\n", (unsigned long long)fnv(download(x)), x.size(),
+               x.scale());
+        PhantomCiphertext r = rescale_to_next(context, x, sw);
+        printf("{\"rescale\": \"%016llx\", \"chain_index\": %zu, \"limbs\": %zu}\n", (unsigned long long)fnv(download(r)),
+               r.chain_index(), r.coeff_modulus_size());
+        // square of a ciphertext at the next level
+        PhantomCiphertext sq = make_ct(context, moduli, 2, 27, 28, s);
+        multiply_inplace(context, sq, sq, sw);
+        relinearize_inplace(context, sq, rlk, sw);
+        printf("{\"square_relin_level2\": \"%016llx\"}\n", (unsigned long long)fnv(download(sq)));
+        // rotate by 1 (key present) and by 3 (NAF: 4 - 1) (tests/rotation.cu)
+        PhantomCiphertext rot = make_ct(context, moduli, 1, 37, 38, s);
+        rotate_inplace(context, rot, 1, gk, sw);
+        printf("{\"rotate1\": \"%016llx\"}\n", (unsigned long long)fnv(download(rot)));
+        PhantomCiphertext rot3 = make_ct(context, moduli, 1, 47, 48, s);
+        rotate_inplace(context, rot3, 3, gk, sw);
+        printf("{\"rotate3_naf\": \"%016llx\"}\n", (unsigned long long)fnv(download(rot3)));
+
+        // error behaviour of the reference
+        int caught = 0;
+        try { relinearize_inplace(context, rot, rlk, sw); } catch (const std::invalid_argument &) { caught++; }
+        try { rotate_inplace(context, rot, 2, gk, sw); } catch (const std::invalid_argument &) { caught++; }
+        try {
+            PhantomCiphertext low = make_ct(context, moduli, 4, 1, 2, s);
+            (void)rescale_to_next(context, low, sw);
+        } catch (const std::invalid_argument &) { caught++; }
+        try { multiply_inplace(context, r, y, sw); } catch (const std::invalid_argument &) { caught++; }
+        try {
+            EncryptionParameters bad = parms;
+            bad.set_poly_modulus_degree(2048);
+            PhantomContext c2(bad);
+        } catch (const std::invalid_argument &) { caught++; }
+        printf("{\"errors_caught\": %d}\n", caught);
+    } catch (const std::exception &e) {
+        printf("{\"fatal\": \"%s\"}\n", e.what());
+        return 1;
+    }
+    return 0;
+}

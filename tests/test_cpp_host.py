@@ -1,0 +1,73 @@
+"""The C++ host layer (phantom-fhe_amd/host/phantom_amd.hpp: PhantomContext, PhantomCiphertext,
+multiply_inplace / relinearize_inplace / rescale_to_next / rotate_inplace with the reference's
+names and error behaviour) driven by a C++ program, checked against the oracle."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+BIN = os.path.join(os.path.dirname(__file__), "cpp", "host_mirror_test")
+
+
+def test_header_only_layer_is_self_contained():
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "phantom-fhe_amd", "host", "phantom_amd.hpp")).read()
+    for name in ("multiply_inplace", "relinearize_inplace", "rescale_to_next", "rotate_inplace", "apply_galois_inplace",
+                 "class PhantomContext", "class PhantomCiphertext", "class PhantomRelinKey", "class PhantomGaloisKey"):
+        assert name in hdr
+    assert "oracle" not in hdr
+
+
+@pytest.mark.gpu
+def test_cpp_host_layer_against_oracle(gpu, orc):
+    assert os.path.exists(BIN), "tests/cpp/host_mirror_test not built (run __graft_entry__.build())"
+    out = subprocess.run([BIN], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    res = {}
+    for line in out.stdout.splitlines():
+        if line.startswith("{"):
+            res.update(json.loads(line))
+    size_p, n = 2, 4096
+    mods = orc.coeff_modulus_create(n, [45, 45, 45, 45, 55, 55])
+    o = orc.Oracle(12, mods, size_p)
+
+    def key(seed):
+        return [np.ascontiguousarray(np.stack([o.uniform_poly(list(range(6)), seed + 10 * d),
+                                               o.uniform_poly(list(range(6)), seed + 10 * d + 1)])) for d in range(2)]
+
+    def ct(limbs, s0, s1):
+        return np.stack([o.uniform_poly(list(range(limbs)), s0), o.uniform_poly(list(range(limbs)), s1)])
+
+    def digest(a):
+        return f"{orc.fnv1a64(np.ascontiguousarray(a)):016x}"
+
+    rlk = key(70)
+    e1, e4, em1 = (orc.galois_elt_from_step(12, s) for s in (1, 4, -1))
+    assert res["galois_elts"] == [e1, e4, em1]
+    gk = {e1: key(170), e4: key(270), em1: key(370)}
+    # multiply + relin + rescale
+    x, y = ct(4, 7, 8), ct(4, 17, 18)
+    tp = o.tensor_prod_2x2(x, y)
+    mr = tp[:2].copy()
+    o.keyswitch_inplace(4, mr, tp[2], rlk)
+    assert res["multiply_relin"] == digest(mr) and res["size"] == 2
+    assert res["scale"] == 1099511627776.0 ** 2
+    rs = o.divide_and_round_q_last_ntt(4, mr, 2)
+    assert res["rescale"] == digest(rs) and res["chain_index"] == 2 and res["limbs"] == 3
+    # square at level 2
+    sq = ct(3, 27, 28)
+    tp = o.tensor_prod_2x2(sq, sq)
+    s2 = tp[:2].copy()
+    o.keyswitch_inplace(3, s2, tp[2], rlk)
+    assert res["square_relin_level2"] == digest(s2)
+
+    def rotate(c, elt):
+        out = np.stack([o.apply_galois_ntt(c[0], elt), np.zeros_like(c[1])])
+        o.keyswitch_inplace(c.shape[1], out, o.apply_galois_ntt(c[1], elt), gk[elt])
+        return out
+
+    assert res["rotate1"] == digest(rotate(ct(4, 37, 38), e1))
+    # step 3 = NAF (-1, +4): applied in that order (least significant digit first)
+    assert res["rotate3_naf"] == digest(rotate(rotate(ct(4, 47, 48), em1), e4))
+    assert res["errors_caught"] == 5
