@@ -152,6 +152,122 @@ __device__ __forceinline__ void gs_butterfly4(uint64_t &x, uint64_t &y, const tw
     y = mul_shoup_lazy4(d, w, m);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Arithmetic policies of the NTT kernels.  A limb is transformed either with the integer lazy
+// butterflies above (any q < 2^61) or, when q < 2^50, with exact integer arithmetic carried in
+// FP64 registers: gfx950 issues v_fma_f64 at full rate while a 64-bit integer modular multiply
+// costs nine quarter-rate 32-bit multiplies (measured 51 vs 84 cycles per butterfly-wave).
+// Both produce the same canonical residues; the choice is a speed matter only.
+// ---------------------------------------------------------------------------------------------
+template <bool NARROW>
+struct IntField {
+    using elem = uint64_t;
+    using twt = tw_t;
+    LazyMod m;
+    __device__ __forceinline__ explicit IntField(const DModulus &mod) : m(mod.value) {}
+    __device__ __forceinline__ elem from_u64(uint64_t v) const { return v; }
+    __device__ __forceinline__ uint64_t to_u64(elem v) const { return v; }
+    __device__ __forceinline__ static uint64_t raw(elem v) { return v; }
+    __device__ __forceinline__ static elem unraw(uint64_t r) { return r; }
+    __device__ __forceinline__ twt make_cst(uint64_t c, uint64_t c_shoup) const { return twt{c, c_shoup}; }
+    // PAR = parity of the stage index within its kernel
+    template <int PAR>
+    __device__ __forceinline__ void ct(elem &x, elem &y, const twt &w) const {
+        if (!NARROW)
+            ct_butterfly8(x, y, w, m);
+        else
+            ct_butterfly16<PAR == 0>(x, y, w, m);
+    }
+    // end of the forward transform: lazy range -> [0,q)
+    __device__ __forceinline__ elem canon_fwd(elem v) const {
+        if (NARROW) v = csub(v, m.q8);
+        return csub(csub(csub(v, m.q4), m.q << 1), m.q);
+    }
+    __device__ __forceinline__ void gs(elem &x, elem &y, const twt &w) const { gs_butterfly4(x, y, w, m); }
+    // last inverse stage: the sum half takes N^-1, the difference half takes itw[1] (which
+    // already holds N^-1, src/util/ntt.cu:53-55); exact-quotient Shoup lands in [0,q)
+    __device__ __forceinline__ void gs_last(elem &x, elem &y, const twt &w, const twt &n_inv) const {
+        const uint64_t a = x, b = y;
+        x = csub(mul_shoup_lazy(a + b, n_inv.x, n_inv.y, m.q), m.q);
+        y = csub(mul_shoup_lazy(a + (m.q4 - b), w.x, w.y, m.q), m.q);
+    }
+    // canonical v -> v * c mod q, canonical
+    __device__ __forceinline__ elem scale(elem v, const twt &c) const { return mul_shoup(v, c.x, c.y, m.q); }
+    // canonical v, sub -> (sub - v) * c mod q, canonical
+    __device__ __forceinline__ elem sub_mul(elem v, uint64_t sub, const twt &c) const {
+        return mul_shoup(csub(sub + m.q - v, m.q), c.x, c.y, m.q);
+    }
+};
+
+// Residues as integer-valued doubles, q < 2^50.  Every intermediate is an integer of magnitude
+// <= 2^52 (or an exactly representable product error term), so each operation below is exact:
+//   mulmod(y, {w, w/q}), |y| <= 2^52:  h = fl(y*w), l = y*w - h (one fma), c = rint(y * (w/q));
+//       |y*w/q - c| <= 1/2 + |y| 2^-52  =>  t = (h - c*q) + l = y*w - c*q,  |t| <= 1.5q + 1
+//   reduce(x): x - rint(x/q)*q, |result| <= q/2 + 1
+struct FpField {
+    using elem = double;
+    using twt = double2;  // {w, w/q}
+    double q, qinv;
+    __device__ __forceinline__ explicit FpField(const DModulus &mod)
+        : q(static_cast<double>(static_cast<int64_t>(mod.value))), qinv(1.0 / q) {}
+    // 0 <= v < 2^52: splice into the mantissa of 2^52 and subtract
+    __device__ __forceinline__ elem from_u64(uint64_t v) const {
+        return __longlong_as_double(static_cast<long long>(v | 0x4330000000000000ull)) - 4503599627370496.0;
+    }
+    // integer-valued 0 <= v < 2^52
+    __device__ __forceinline__ uint64_t to_u64(elem v) const {
+        return static_cast<uint64_t>(__double_as_longlong(v + 4503599627370496.0)) & 0x000FFFFFFFFFFFFFull;
+    }
+    __device__ __forceinline__ static uint64_t raw(elem v) { return static_cast<uint64_t>(__double_as_longlong(v)); }
+    __device__ __forceinline__ static elem unraw(uint64_t r) { return __longlong_as_double(static_cast<long long>(r)); }
+    __device__ __forceinline__ twt make_cst(uint64_t c, uint64_t) const {
+        const double w = from_u64(c);
+        return twt{w, w * qinv};
+    }
+    __device__ __forceinline__ elem mulmod(elem y, const twt &w) const {
+#pragma clang fp contract(off)
+        const double h = y * w.x;
+        const double l = __builtin_fma(y, w.x, -h);
+        const double c = __builtin_rint(y * w.y);
+        return __builtin_fma(-c, q, h) + l;
+    }
+    __device__ __forceinline__ elem reduce(elem x) const {
+#pragma clang fp contract(off)
+        return __builtin_fma(-__builtin_rint(x * qinv), q, x);
+    }
+    // any |v| <= 2^52 -> [0,q)
+    __device__ __forceinline__ elem canon(elem v) const {
+        const double r = reduce(v);
+        return r < 0.0 ? r + q : r;
+    }
+    // Forward butterfly.  Even stage: x is reduced (|u| <= q/2+1), |y| <= 4q -> outputs <= 2q+2;
+    // odd stage: inputs <= 2q+2 -> outputs <= 3.5q+3 < 4q <= 2^52.  API inputs may be lazy up to
+    // 4q like the reference's (they enter an even stage).
+    template <int PAR>
+    __device__ __forceinline__ void ct(elem &x, elem &y, const twt &w) const {
+        const double t = mulmod(y, w);
+        const double u = PAR == 0 ? reduce(x) : x;
+        x = u + t;
+        y = u - t;
+    }
+    __device__ __forceinline__ elem canon_fwd(elem v) const { return canon(v); }
+    // Inverse butterfly: inputs |.| <= q+2 -> sum reduced to <= q/2+1, product <= q+1
+    __device__ __forceinline__ void gs(elem &x, elem &y, const twt &w) const {
+        const double d = x - y;
+        x = reduce(x + y);
+        y = mulmod(d, w);
+    }
+    __device__ __forceinline__ void gs_last(elem &x, elem &y, const twt &w, const twt &n_inv) const {
+        const double a = x + y, b = x - y;
+        x = canon(mulmod(a, n_inv));
+        y = canon(mulmod(b, w));
+    }
+    __device__ __forceinline__ elem scale(elem v, const twt &c) const { return canon(mulmod(v, c)); }
+    __device__ __forceinline__ elem sub_mul(elem v, uint64_t sub, const twt &c) const {
+        return canon(mulmod(from_u64(sub) - v, c));
+    }
+};
+
 // Harvey forward butterfly, x,y in [0,4q) -> [0,4q)  (include/butterfly.cuh:10-22)
 __device__ __forceinline__ void ct_butterfly(uint64_t &x, uint64_t &y, const tw_t &w, uint64_t q, uint64_t q2) {
     const uint64_t t = mul_shoup_lazy(y, w.x, w.y, q);

@@ -40,6 +40,7 @@ struct NttTables {
     const uint64_t *n_inv, *n_inv_shoup;  // [size_QP]
     uint32_t log_n;
     uint32_t twD_stride;   // records per limb in twD
+    uint32_t fp64;         // limbs with q < 2^50 hold {double w, double w/q} records and run on FpField
 };
 
 // out[l][e] = (sub[l][e] - x) * cst[l] (+ addend[l][e])   or   x * cst[l]
@@ -84,39 +85,37 @@ __device__ __forceinline__ void decode_block(uint32_t b, uint32_t polys, uint32_
     }
 }
 
+template <class TW>
 struct CanonTw {
-    const tw_t *tw;
+    const TW *tw;
     uint32_t node;
-    __device__ __forceinline__ tw_t operator()(int s, int jb) const { return tw[(node << s) + jb]; }
+    __device__ __forceinline__ TW operator()(int s, int jb) const { return tw[(node << s) + jb]; }
 };
 
-template <int RB>
+template <int RB, class TW>
 struct LastPassTw {
-    const tw_t *base;  // already offset to (chunk, lane)
-    __device__ __forceinline__ tw_t operator()(int s, int jb) const { return base[((1 << s) - 1 + jb) * 64]; }
+    const TW *base;  // already offset to (chunk, lane)
+    __device__ __forceinline__ TW operator()(int s, int jb) const { return base[((1 << s) - 1 + jb) * 64]; }
 };
 
 // radix-2^R decimation-in-time block: stage s uses twiddle node*2^s + jb on sub-block jb.
-// G0 = index of the block's first stage within its kernel.  NARROW (every modulus < 2^60): lazy
-// range [0,16q), conditional subtraction on even kernel-local stages only; otherwise range
-// [0,8q) with a conditional subtraction every stage.
-template <int R, int G0, bool NARROW, class Tw>
-__device__ __forceinline__ void ct_radix(uint64_t (&x)[1 << R], const Tw &tw, const LazyMod &m) {
+// G0 = index of the block's first stage within its kernel; the field policies (modarith.cuh)
+// reduce on even kernel-local stages only.
+template <int R, int G0, class F, class Tw>
+__device__ __forceinline__ void ct_radix(typename F::elem (&x)[1 << R], const Tw &tw, const F &f) {
 #pragma unroll
     for (int s = 0; s < R; s++) {
         const int half = 1 << (R - 1 - s);
 #pragma unroll
         for (int jb = 0; jb < (1 << s); jb++) {
-            const tw_t w = tw(s, jb);
+            const typename F::twt w = tw(s, jb);
 #pragma unroll
             for (int i = 0; i < half; i++) {
-                uint64_t &a = x[jb * 2 * half + i], &b = x[jb * 2 * half + half + i];
-                if (!NARROW)
-                    ct_butterfly8(a, b, w, m);
-                else if (((G0 + s) & 1) == 0)
-                    ct_butterfly16<true>(a, b, w, m);
+                typename F::elem &a = x[jb * 2 * half + i], &b = x[jb * 2 * half + half + i];
+                if (((G0 + s) & 1) == 0)
+                    f.template ct<0>(a, b, w);
                 else
-                    ct_butterfly16<false>(a, b, w, m);
+                    f.template ct<1>(a, b, w);
             }
         }
     }
@@ -124,29 +123,24 @@ __device__ __forceinline__ void ct_radix(uint64_t (&x)[1 << R], const Tw &tw, co
 
 // inverse block; LAST: the final stage multiplies the sum half by N^-1 (the difference half gets
 // it through itw[1], src/util/ntt.cu:53-55) and reduces everything to [0,q)
-template <int R, bool LAST, class Tw>
-__device__ __forceinline__ void gs_radix(uint64_t (&x)[1 << R], const Tw &tw, const LazyMod &m, uint64_t n_inv = 0,
-                                         uint64_t n_inv_shoup = 0) {
+template <int R, bool LAST, class F, class Tw>
+__device__ __forceinline__ void gs_radix(typename F::elem (&x)[1 << R], const Tw &tw, const F &f,
+                                         const typename F::twt &n_inv) {
 #pragma unroll
     for (int s = R - 1; s >= (LAST ? 1 : 0); s--) {
         const int half = 1 << (R - 1 - s);
 #pragma unroll
         for (int jb = 0; jb < (1 << s); jb++) {
-            const tw_t w = tw(s, jb);
+            const typename F::twt w = tw(s, jb);
 #pragma unroll
-            for (int i = 0; i < half; i++) gs_butterfly4(x[jb * 2 * half + i], x[jb * 2 * half + half + i], w, m);
+            for (int i = 0; i < half; i++) f.gs(x[jb * 2 * half + i], x[jb * 2 * half + half + i], w);
         }
     }
     if (LAST) {
         const int half = 1 << (R - 1);
-        const tw_t w = tw(0, 0);
+        const typename F::twt w = tw(0, 0);
 #pragma unroll
-        for (int i = 0; i < half; i++) {
-            const uint64_t a = x[i], b = x[half + i];
-            // exact-quotient Shoup here: one conditional subtraction lands in [0,q)
-            x[i] = csub(mul_shoup_lazy(a + b, n_inv, n_inv_shoup, m.q), m.q);
-            x[half + i] = csub(mul_shoup_lazy(a + (m.q4 - b), w.x, w.y, m.q), m.q);
-        }
+        for (int i = 0; i < half; i++) f.gs_last(x[i], x[half + i], w, n_inv);
     }
 }
 
@@ -162,12 +156,48 @@ __device__ __forceinline__ uint32_t lds_col(uint32_t r, uint32_t c) {
 // is conflict-free.
 __device__ __forceinline__ uint32_t lds_row(uint32_t e) { return e + ((e >> 4) << 1); }
 
+// Between the two kernels of a transform the buffer holds the field's raw lazy representation
+// (an unreduced integer, or the bits of a double on the FP64 path); only the first kernel's
+// input and the last kernel's output are residues in the caller's format.
+__device__ __forceinline__ bool use_fp64(const NttTables &T, const DModulus &mod) {
+    return T.fp64 && (mod.value >> 50) == 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward, column phase: stages m = 1 .. 2^(S1-1)
 // ---------------------------------------------------------------------------------------------
+template <int S1, int RA, class F>
+__device__ __forceinline__ void fntt_col_body(uint64_t *lds, uint64_t *base, const tw_t *tw_raw, uint32_t n2, const F &f) {
+    constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
+    using TW = typename F::twt;
+    const TW *tw = reinterpret_cast<const TW *>(tw_raw);
+    const uint32_t t = threadIdx.x;
+#pragma unroll
+    for (int g = 0; g < GA; g++) {
+        const uint32_t gid = t + kThreads * g, c = gid % C, r_lo = gid / C;
+        typename F::elem x[1 << RA];
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) x[j] = f.from_u64(base[static_cast<size_t>((j << RB) | r_lo) * n2 + c]);
+        ct_radix<RA, 0>(x, CanonTw<TW>{tw, 1u}, f);
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) lds[lds_col<C, RB>((j << RB) | r_lo, c)] = F::raw(x[j]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GB; g++) {
+        const uint32_t gid = t + kThreads * g, c = gid % C, r_hi = gid / C;
+        typename F::elem x[1 << RB];
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(lds[lds_col<C, RB>((r_hi << RB) | j, c)]);
+        ct_radix<RB, RA>(x, CanonTw<TW>{tw, (1u << RA) + r_hi}, f);
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) base[static_cast<size_t>((r_hi << RB) | j) * n2 + c] = F::raw(x[j]);
+    }
+}
+
 template <int S1, int RA, bool NARROW>
 __global__ __launch_bounds__(kThreads) void fntt_col_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm) {
-    constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
+    constexpr int C = kTile >> S1;
     __shared__ uint64_t lds[kLdsWords];
     const uint32_t n = 1u << T.log_n, n2 = n >> S1, tiles = n >> 12;
     uint32_t poly, tile;
@@ -176,41 +206,80 @@ __global__ __launch_bounds__(kThreads) void fntt_col_kernel(uint64_t *data, size
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, li, twr, tidx)) return;
     uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + ti * C;
-    const uint64_t q = T.mod[tidx].value;
-    const LazyMod lmod(q);
+    const DModulus mod = T.mod[tidx];
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
-    const uint32_t t = threadIdx.x;
-
-#pragma unroll
-    for (int g = 0; g < GA; g++) {
-        const uint32_t gid = t + kThreads * g, c = gid % C, r_lo = gid / C;
-        uint64_t x[1 << RA];
-#pragma unroll
-        for (int j = 0; j < (1 << RA); j++) x[j] = base[static_cast<size_t>((j << RB) | r_lo) * n2 + c];
-        ct_radix<RA, 0, NARROW>(x, CanonTw{tw, 1u}, lmod);
-#pragma unroll
-        for (int j = 0; j < (1 << RA); j++) lds[lds_col<C, RB>((j << RB) | r_lo, c)] = x[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < GB; g++) {
-        const uint32_t gid = t + kThreads * g, c = gid % C, r_hi = gid / C;
-        uint64_t x[1 << RB];
-#pragma unroll
-        for (int j = 0; j < (1 << RB); j++) x[j] = lds[lds_col<C, RB>((r_hi << RB) | j, c)];
-        ct_radix<RB, RA, NARROW>(x, CanonTw{tw, (1u << RA) + r_hi}, lmod);
-#pragma unroll
-        for (int j = 0; j < (1 << RB); j++) base[static_cast<size_t>((r_hi << RB) | j) * n2 + c] = x[j];
-    }
+    if (use_fp64(T, mod))
+        fntt_col_body<S1, RA>(lds, base, tw, n2, FpField(mod));
+    else
+        fntt_col_body<S1, RA>(lds, base, tw, n2, IntField<NARROW>(mod));
 }
 
 // ---------------------------------------------------------------------------------------------
 // forward, row phase: stages m = 2^S1 .. N/2, final reduction to [0,q), optional fused epilogue
 // ---------------------------------------------------------------------------------------------
+template <int S2, int RA, int EPI, class F>
+__device__ __forceinline__ void fntt_row_body(uint64_t *lds, uint64_t *base, const tw_t *tw_raw, const tw_t *twd_raw,
+                                              uint32_t n1, uint32_t ti, const F &f, uint64_t q, uint64_t *out,
+                                              const uint64_t *sub, const uint64_t *addend, uint64_t cst,
+                                              uint64_t cst_shoup) {
+    constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
+    using TW = typename F::twt;
+    const TW *tw = reinterpret_cast<const TW *>(tw_raw);
+    const uint32_t t = threadIdx.x;
+#pragma unroll
+    for (int g = 0; g < GC; g++) {
+        const uint32_t gid = t + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;
+        typename F::elem x[1 << RA];
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) x[j] = F::unraw(base[a * L + ((j << RB) | b_lo)]);
+        ct_radix<RA, 0>(x, CanonTw<TW>{tw, n1 + ti * RW + a}, f);
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) lds[lds_row(a * L + ((j << RB) | b_lo))] = F::raw(x[j]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GD; g++) {
+        const uint32_t gid = t + kThreads * g, e0 = gid << RB;
+        const uint32_t ggid = ti * (kTile >> RB) + gid;
+        typename F::elem x[1 << RB];
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(lds[lds_row(e0 + j)]);
+        const TW *twd = reinterpret_cast<const TW *>(twd_raw) +
+                        static_cast<size_t>(ggid >> 6) * (((1 << RB) - 1) * 64) + (ggid & 63);
+        ct_radix<RB, RA>(x, LastPassTw<RB, TW>{twd}, f);
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) lds[lds_row(e0 + j)] = F::raw(f.canon_fwd(x[j]));
+    }
+    __syncthreads();
+
+    const TW c = f.make_cst(cst, cst_shoup);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t e = (i * kThreads + t) * 2;
+        typename F::elem v0 = F::unraw(lds[lds_row(e)]), v1 = F::unraw(lds[lds_row(e + 1)]);
+        ulonglong2 v;
+        if (EPI != EPI_NONE) {
+            // (cx - NTT(delta)) * PInv mod q  (src/ntt/ntt_moddown.cu:209-214,
+            // include/uintmodmath.cuh:234-242); same shape for rescale (src/rns.cu:1138-1155)
+            const ulonglong2 s = *reinterpret_cast<const ulonglong2 *>(sub + e);
+            v.x = f.to_u64(f.sub_mul(v0, s.x, c));
+            v.y = f.to_u64(f.sub_mul(v1, s.y, c));
+            if (EPI == EPI_SUB_MUL_ADD) {
+                const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(addend + e);
+                v.x = csub(v.x + a.x, q);
+                v.y = csub(v.y + a.y, q);
+            }
+        } else {
+            v.x = f.to_u64(v0);
+            v.y = f.to_u64(v1);
+        }
+        *reinterpret_cast<ulonglong2 *>(out + e) = v;
+    }
+}
+
 template <int S2, int RA, int EPI, bool NARROW>
 __global__ __launch_bounds__(kThreads) void fntt_row_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm,
                                                             Epilogue ep) {
-    constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
     __shared__ uint64_t lds[kLdsWords];
     const uint32_t n = 1u << T.log_n, n1 = n >> S2, tiles = n >> 12;
     uint32_t poly, tile;
@@ -221,40 +290,8 @@ __global__ __launch_bounds__(kThreads) void fntt_row_kernel(uint64_t *data, size
     const size_t limb_off = static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
     uint64_t *base = data + poly * poly_stride + limb_off;
     const DModulus mod = T.mod[tidx];
-    const uint64_t q = mod.value;
-    const LazyMod lmod(q);
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
-    const uint32_t t = threadIdx.x;
-
-#pragma unroll
-    for (int g = 0; g < GC; g++) {
-        const uint32_t gid = t + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;
-        uint64_t x[1 << RA];
-#pragma unroll
-        for (int j = 0; j < (1 << RA); j++) x[j] = base[a * L + ((j << RB) | b_lo)];
-        ct_radix<RA, 0, NARROW>(x, CanonTw{tw, n1 + ti * RW + a}, lmod);
-#pragma unroll
-        for (int j = 0; j < (1 << RA); j++) lds[lds_row(a * L + ((j << RB) | b_lo))] = x[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < GD; g++) {
-        const uint32_t gid = t + kThreads * g, e0 = gid << RB;
-        const uint32_t ggid = ti * (kTile >> RB) + gid;
-        uint64_t x[1 << RB];
-#pragma unroll
-        for (int j = 0; j < (1 << RB); j++) x[j] = lds[lds_row(e0 + j)];
-        const tw_t *twd = T.twD + static_cast<size_t>(tidx) * T.twD_stride +
-                          static_cast<size_t>(ggid >> 6) * (((1 << RB) - 1) * 64) + (ggid & 63);
-        ct_radix<RB, RA, NARROW>(x, LastPassTw<RB>{twd}, lmod);
-#pragma unroll
-        for (int j = 0; j < (1 << RB); j++) {
-            uint64_t v = x[j];
-            if (NARROW) v = csub(v, lmod.q8);
-            lds[lds_row(e0 + j)] = csub(csub(csub(v, lmod.q4), q << 1), q);
-        }
-    }
-    __syncthreads();
+    const tw_t *twd = T.twD + static_cast<size_t>(tidx) * T.twD_stride;
 
     uint64_t *out = base;
     const uint64_t *sub = nullptr, *addend = nullptr;
@@ -266,35 +303,61 @@ __global__ __launch_bounds__(kThreads) void fntt_row_kernel(uint64_t *data, size
         cst = ep.cst[twr];
         cst_shoup = ep.cst_shoup[twr];
     }
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t e = (i * kThreads + t) * 2;
-        ulonglong2 v;
-        v.x = lds[lds_row(e)];
-        v.y = lds[lds_row(e + 1)];
-        if (EPI != EPI_NONE) {
-            // (cx - NTT(delta)) * PInv mod q  (src/ntt/ntt_moddown.cu:209-214,
-            // include/uintmodmath.cuh:234-242); same shape for rescale (src/rns.cu:1138-1155)
-            const ulonglong2 s = *reinterpret_cast<const ulonglong2 *>(sub + e);
-            v.x = mul_shoup(csub(s.x + q - v.x, q), cst, cst_shoup, q);
-            v.y = mul_shoup(csub(s.y + q - v.y, q), cst, cst_shoup, q);
-            if (EPI == EPI_SUB_MUL_ADD) {
-                const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(addend + e);
-                v.x = csub(v.x + a.x, q);
-                v.y = csub(v.y + a.y, q);
-            }
-        }
-        *reinterpret_cast<ulonglong2 *>(out + e) = v;
-    }
+    if (use_fp64(T, mod))
+        fntt_row_body<S2, RA, EPI>(lds, base, tw, twd, n1, ti, FpField(mod), mod.value, out, sub, addend, cst, cst_shoup);
+    else
+        fntt_row_body<S2, RA, EPI>(lds, base, tw, twd, n1, ti, IntField<NARROW>(mod), mod.value, out, sub, addend, cst,
+                                   cst_shoup);
 }
 
 // ---------------------------------------------------------------------------------------------
 // inverse, row phase (first): stages m = N/2 .. 2^S1
 // ---------------------------------------------------------------------------------------------
+template <int S2, int RA, class F>
+__device__ __forceinline__ void intt_row_body(uint64_t *lds, uint64_t *dst, const uint64_t *src, const tw_t *tw_raw,
+                                              const tw_t *twd_raw, uint32_t n1, uint32_t ti, const F &f) {
+    constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
+    using TW = typename F::twt;
+    const TW *tw = reinterpret_cast<const TW *>(tw_raw);
+    const uint32_t t = threadIdx.x;
+    const TW unused{};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t e = (i * kThreads + t) * 2;
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + e);
+        lds[lds_row(e)] = F::raw(f.from_u64(v.x));
+        lds[lds_row(e + 1)] = F::raw(f.from_u64(v.y));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GD; g++) {
+        const uint32_t gid = t + kThreads * g, e0 = gid << RB;
+        const uint32_t ggid = ti * (kTile >> RB) + gid;
+        typename F::elem x[1 << RB];
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(lds[lds_row(e0 + j)]);
+        const TW *twd = reinterpret_cast<const TW *>(twd_raw) +
+                        static_cast<size_t>(ggid >> 6) * (((1 << RB) - 1) * 64) + (ggid & 63);
+        gs_radix<RB, false>(x, LastPassTw<RB, TW>{twd}, f, unused);
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) lds[lds_row(e0 + j)] = F::raw(x[j]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GC; g++) {
+        const uint32_t gid = t + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;
+        typename F::elem x[1 << RA];
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) x[j] = F::unraw(lds[lds_row(a * L + ((j << RB) | b_lo))]);
+        gs_radix<RA, false>(x, CanonTw<TW>{tw, n1 + ti * RW + a}, f, unused);
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) dst[a * L + ((j << RB) | b_lo)] = F::raw(x[j]);
+    }
+}
+
 template <int S2, int RA>
 __global__ __launch_bounds__(kThreads) void intt_row_kernel(uint64_t *out, const uint64_t *in, size_t poly_stride,
                                                             NttTables T, LimbMap lm) {
-    constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
     __shared__ uint64_t lds[kLdsWords];
     const uint32_t n = 1u << T.log_n, n1 = n >> S2, tiles = n >> 12;
     uint32_t poly, tile;
@@ -303,54 +366,59 @@ __global__ __launch_bounds__(kThreads) void intt_row_kernel(uint64_t *out, const
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, li, twr, tidx)) return;
     const size_t off = poly * poly_stride + static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
-    const uint64_t *src = in + off;
-    uint64_t *dst = out + off;
-    const uint64_t q = T.mod[tidx].value;
-    const LazyMod lmod(q);
+    const DModulus mod = T.mod[tidx];
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
-    const uint32_t t = threadIdx.x;
-
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t e = (i * kThreads + t) * 2;
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + e);
-        lds[lds_row(e)] = v.x;
-        lds[lds_row(e + 1)] = v.y;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < GD; g++) {
-        const uint32_t gid = t + kThreads * g, e0 = gid << RB;
-        const uint32_t ggid = ti * (kTile >> RB) + gid;
-        uint64_t x[1 << RB];
-#pragma unroll
-        for (int j = 0; j < (1 << RB); j++) x[j] = lds[lds_row(e0 + j)];
-        const tw_t *twd = T.twD + static_cast<size_t>(tidx) * T.twD_stride +
-                          static_cast<size_t>(ggid >> 6) * (((1 << RB) - 1) * 64) + (ggid & 63);
-        gs_radix<RB, false>(x, LastPassTw<RB>{twd}, lmod);
-#pragma unroll
-        for (int j = 0; j < (1 << RB); j++) lds[lds_row(e0 + j)] = x[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < GC; g++) {
-        const uint32_t gid = t + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;
-        uint64_t x[1 << RA];
-#pragma unroll
-        for (int j = 0; j < (1 << RA); j++) x[j] = lds[lds_row(a * L + ((j << RB) | b_lo))];
-        gs_radix<RA, false>(x, CanonTw{tw, n1 + ti * RW + a}, lmod);
-#pragma unroll
-        for (int j = 0; j < (1 << RA); j++) dst[a * L + ((j << RB) | b_lo)] = x[j];
-    }
+    const tw_t *twd = T.twD + static_cast<size_t>(tidx) * T.twD_stride;
+    if (use_fp64(T, mod))
+        intt_row_body<S2, RA>(lds, out + off, in + off, tw, twd, n1, ti, FpField(mod));
+    else
+        intt_row_body<S2, RA>(lds, out + off, in + off, tw, twd, n1, ti, IntField<true>(mod));
 }
 
 // ---------------------------------------------------------------------------------------------
 // inverse, column phase (last): stages m = 2^(S1-1) .. 1, N^-1, reduction to [0,q), optional scale
 // ---------------------------------------------------------------------------------------------
+template <int S1, int RA, int EPI, class F>
+__device__ __forceinline__ void intt_col_body(uint64_t *lds, uint64_t *base, const tw_t *tw_raw, uint32_t n2, const F &f,
+                                              uint64_t n_inv, uint64_t n_inv_shoup, uint64_t cst, uint64_t cst_shoup) {
+    constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
+    using TW = typename F::twt;
+    const TW *tw = reinterpret_cast<const TW *>(tw_raw);
+    const uint32_t t = threadIdx.x;
+    const TW ninv = f.make_cst(n_inv, n_inv_shoup);
+#pragma unroll
+    for (int g = 0; g < GB; g++) {
+        const uint32_t gid = t + kThreads * g, c = gid % C, r_hi = gid / C;
+        typename F::elem x[1 << RB];
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(base[static_cast<size_t>((r_hi << RB) | j) * n2 + c]);
+        gs_radix<RB, false>(x, CanonTw<TW>{tw, (1u << RA) + r_hi}, f, ninv);
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) lds[lds_col<C, RB>((r_hi << RB) | j, c)] = F::raw(x[j]);
+    }
+    __syncthreads();
+    const TW c_scale = f.make_cst(cst, cst_shoup);
+#pragma unroll
+    for (int g = 0; g < GA; g++) {
+        const uint32_t gid = t + kThreads * g, c = gid % C, r_lo = gid / C;
+        typename F::elem x[1 << RA];
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) x[j] = F::unraw(lds[lds_col<C, RB>((j << RB) | r_lo, c)]);
+        gs_radix<RA, true>(x, CanonTw<TW>{tw, 1u}, f, ninv);
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) {
+            typename F::elem v = x[j];
+            // fused bconv phase 1 (src/ntt/ntt_modup.cu:212-318)
+            if (EPI == EPI_SCALE) v = f.scale(v, c_scale);
+            base[static_cast<size_t>((j << RB) | r_lo) * n2 + c] = f.to_u64(v);
+        }
+    }
+}
+
 template <int S1, int RA, int EPI>
 __global__ __launch_bounds__(kThreads) void intt_col_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm,
                                                             Epilogue ep) {
-    constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
+    constexpr int C = kTile >> S1;
     __shared__ uint64_t lds[kLdsWords];
     const uint32_t n = 1u << T.log_n, n2 = n >> S1, tiles = n >> 12;
     uint32_t poly, tile;
@@ -359,43 +427,18 @@ __global__ __launch_bounds__(kThreads) void intt_col_kernel(uint64_t *data, size
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, li, twr, tidx)) return;
     uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + ti * C;
-    const uint64_t q = T.mod[tidx].value;
-    const LazyMod lmod(q);
+    const DModulus mod = T.mod[tidx];
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
-    const uint32_t t = threadIdx.x;
-
-#pragma unroll
-    for (int g = 0; g < GB; g++) {
-        const uint32_t gid = t + kThreads * g, c = gid % C, r_hi = gid / C;
-        uint64_t x[1 << RB];
-#pragma unroll
-        for (int j = 0; j < (1 << RB); j++) x[j] = base[static_cast<size_t>((r_hi << RB) | j) * n2 + c];
-        gs_radix<RB, false>(x, CanonTw{tw, (1u << RA) + r_hi}, lmod);
-#pragma unroll
-        for (int j = 0; j < (1 << RB); j++) lds[lds_col<C, RB>((r_hi << RB) | j, c)] = x[j];
-    }
-    __syncthreads();
     const uint64_t n_inv = T.n_inv[tidx], n_inv_shoup = T.n_inv_shoup[tidx];
     uint64_t cst = 0, cst_shoup = 0;
     if (EPI == EPI_SCALE) {
         cst = ep.cst[twr];
         cst_shoup = ep.cst_shoup[twr];
     }
-#pragma unroll
-    for (int g = 0; g < GA; g++) {
-        const uint32_t gid = t + kThreads * g, c = gid % C, r_lo = gid / C;
-        uint64_t x[1 << RA];
-#pragma unroll
-        for (int j = 0; j < (1 << RA); j++) x[j] = lds[lds_col<C, RB>((j << RB) | r_lo, c)];
-        gs_radix<RA, true>(x, CanonTw{tw, 1u}, lmod, n_inv, n_inv_shoup);
-#pragma unroll
-        for (int j = 0; j < (1 << RA); j++) {
-            uint64_t v = x[j];
-            // fused bconv phase 1 (src/ntt/ntt_modup.cu:212-318)
-            if (EPI == EPI_SCALE) v = mul_shoup(v, cst, cst_shoup, q);
-            base[static_cast<size_t>((j << RB) | r_lo) * n2 + c] = v;
-        }
-    }
+    if (use_fp64(T, mod))
+        intt_col_body<S1, RA, EPI>(lds, base, tw, n2, FpField(mod), n_inv, n_inv_shoup, cst, cst_shoup);
+    else
+        intt_col_body<S1, RA, EPI>(lds, base, tw, n2, IntField<true>(mod), n_inv, n_inv_shoup, cst, cst_shoup);
 }
 
 }  // namespace pha

@@ -115,6 +115,7 @@ struct pha_context {
     size_t n = 0, size_QP = 0, size_P = 0, size_Q = 0;
     NttPlan plan{};
     bool narrow = false;  // every modulus < 2^60: forward butterflies use the 16q lazy range
+    bool fp64 = true;     // limbs with q < 2^50 run on the FP64 butterflies (PHA_DISABLE_FP64=1 turns it off)
     std::vector<uint64_t> moduli;
     std::vector<LimbTables> host_tables;
     DevBuf<DModulus> d_mod;
@@ -126,11 +127,14 @@ struct pha_context {
     DevBuf<uint64_t> workspace;
 
     NttTables fwd_tables() const {
-        return NttTables{d_mod.p, d_tw.p, d_twD.p, d_n_inv.p, d_n_inv_shoup.p, static_cast<uint32_t>(log_n), twD_stride};
+        return NttTables{d_mod.p, d_tw.p, d_twD.p, d_n_inv.p, d_n_inv_shoup.p, static_cast<uint32_t>(log_n), twD_stride,
+                         fp64 ? 1u : 0u};
     }
     NttTables inv_tables() const {
-        return NttTables{d_mod.p, d_itw.p, d_itwD.p, d_n_inv.p, d_n_inv_shoup.p, static_cast<uint32_t>(log_n), twD_stride};
+        return NttTables{d_mod.p, d_itw.p, d_itwD.p, d_n_inv.p, d_n_inv_shoup.p, static_cast<uint32_t>(log_n), twD_stride,
+                         fp64 ? 1u : 0u};
     }
+    bool limb_is_fp64(size_t l) const { return fp64 && (moduli[l] >> 50) == 0; }
 };
 
 namespace {
@@ -169,6 +173,17 @@ void last_pass_order(const tw_t *canon, size_t n, int rb, tw_t *dst) {
     }
 }
 
+// {w, w_shoup} -> {double(w), double(w) / double(q)} for the limbs that run on FpField (same
+// 16-byte records, same order)
+void to_fp64_records(tw_t *rec, size_t count, uint64_t q) {
+    const double dq = static_cast<double>(q);
+    for (size_t i = 0; i < count; i++) {
+        const double w = static_cast<double>(rec[i].x), wq = w / dq;
+        memcpy(&rec[i].x, &w, sizeof(double));
+        memcpy(&rec[i].y, &wq, sizeof(double));
+    }
+}
+
 int upload_tables(pha_context *ctx) {
     const size_t n = ctx->n, L = ctx->size_QP;
     const int rb = ctx->plan.s2 - ctx->plan.ra2;
@@ -183,6 +198,12 @@ int upload_tables(pha_context *ctx) {
         interleave(t.itw, t.itw_shoup, itw.data() + l * n);
         last_pass_order(tw.data() + l * n, n, rb, twD.data() + l * stride);
         last_pass_order(itw.data() + l * n, n, rb, itwD.data() + l * stride);
+        if (ctx->limb_is_fp64(l)) {
+            to_fp64_records(tw.data() + l * n, n, t.q);
+            to_fp64_records(itw.data() + l * n, n, t.q);
+            to_fp64_records(twD.data() + l * stride, stride, t.q);
+            to_fp64_records(itwD.data() + l * stride, stride, t.q);
+        }
         mods[l] = DModulus{t.q, t.ratio[0], t.ratio[1]};
         ninv[l] = t.n_inv;
         ninv_s[l] = t.n_inv_shoup;
@@ -637,6 +658,8 @@ int pha_context_create(int log_n, const uint64_t *moduli_QP, size_t size_QP, siz
     ctx->size_Q = size_QP - size_P;
     ctx->plan = plan;
     ctx->moduli.assign(moduli_QP, moduli_QP + size_QP);
+    const char *no_fp = getenv("PHA_DISABLE_FP64");
+    ctx->fp64 = !(no_fp && no_fp[0] == '1');
     ctx->narrow = true;
     for (size_t i = 0; i < size_QP; i++) ctx->narrow = ctx->narrow && (moduli_QP[i] >> 60) == 0;
     ctx->host_tables.resize(size_QP);
@@ -675,6 +698,17 @@ int pha_context_get_table(const pha_context *ctx, size_t limb, int which, uint64
     const tw_t *src = (which < 2 ? ctx->d_tw.p : ctx->d_itw.p) + limb * ctx->n;
     std::vector<tw_t> h(ctx->n);
     HIP_TRY(hipMemcpy(h.data(), src, ctx->n * sizeof(tw_t), hipMemcpyDeviceToHost));
+    if (ctx->limb_is_fp64(limb)) {
+        // FP64 limbs keep {double w, double w/q}: the value comes back from the device, its Shoup
+        // companion (unused by the kernels on such a limb) from the host tables
+        const LimbTables &t = ctx->host_tables[limb];
+        for (size_t i = 0; i < ctx->n; i++) {
+            double w;
+            memcpy(&w, &h[i].x, sizeof(double));
+            out_host[i] = (which & 1) ? (which == 1 ? t.tw_shoup[i] : t.itw_shoup[i]) : static_cast<uint64_t>(w);
+        }
+        return PHA_OK;
+    }
     for (size_t i = 0; i < ctx->n; i++) out_host[i] = (which & 1) ? h[i].y : h[i].x;
     return PHA_OK;
 }
