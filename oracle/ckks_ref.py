@@ -1,0 +1,208 @@
+"""TEST INFRASTRUCTURE ONLY — scheme-level harness around the CPU oracle.
+
+The reference pins its hot path only functionally: every test in tests/{multi,relin,rotation,
+rescale_to_next,apply_galois}.cu checks decrypt(op(encrypt(x))) ~= op(x).  This
+module restates, on the CPU, just enough of the reference's key generation / encryption /
+decryption to drive the same kind of check against this repository's key switch, with *real*
+keys instead of uniform stand-ins:
+
+* secret key: ternary coefficients, NTT form over all key-level limbs
+  (src/secretkey.cu:368-440 gen_secretkey)
+* encrypt_zero_symmetric: (c0, c1) = (-(a*s + e), a) in NTT form (src/secretkey.cu:207-263)
+* key-switching key for a new key s': dnum = size_Q / size_P ciphertexts of zero at key level
+  whose b-part receives (P mod q_j) * s'_j on limbs j in [d*alpha, (d+1)*alpha)
+  (src/secretkey.cu:265-310, src/polymath.cu:323-343)
+* relin key: s' = s^2 (src/secretkey.cu gen_relinkey); Galois key: s' = s(X^g)
+  (src/secretkey.cu create_galois_keys, src/galois.cu:42-75 coefficient-form automorphism)
+* decrypt: sum_i c_i * s^i, INTT, CRT-compose, centre (src/secretkey.cu decrypt / ckks decode)
+
+Randomness is a seeded numpy generator (the reference uses std::random_device + a stream
+cipher; the distributions — uniform, ternary, rounded Gaussian sigma 3.2 — are what matters for
+a functional check).  Plaintexts are integer polynomials scaled by Delta (coefficient packing),
+which exercises exactly the same ciphertext arithmetic as the canonical-embedding encoder
+without the FFT.
+"""
+import numpy as np
+
+from . import Oracle
+
+
+def _mulmod_vec(a, b, q):
+    """(a * b) mod q for uint64 vectors, exact (Python integers on object arrays)."""
+    return np.array((a.astype(object) * b.astype(object)) % int(q), dtype=np.uint64)
+
+
+def _pointwise(orc, a, b, tidx):
+    """limb-wise product of two NTT-form polynomials; limb i is modulo moduli[tidx[i]]"""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.zeros_like(a)
+    for i, t in enumerate(tidx):
+        out[i] = _mulmod_vec(a[i], b[i], orc.moduli[t])
+    return out
+
+
+class CkksHarness:
+    """Key material and encrypt/decrypt for one key-level context (Oracle)."""
+
+    def __init__(self, orc: Oracle, seed=1, sigma=3.2):
+        self.orc = orc
+        self.n = orc.n
+        self.rng = np.random.default_rng(seed)
+        self.sigma = sigma
+        self._uniform_seed = seed * 7919 + 11
+        self.s = self.rng.integers(-1, 2, size=self.n).astype(np.int64)  # ternary
+        self.sk_ntt = self.to_ntt(self.s, range(orc.size_QP))
+
+    # ---- representation helpers ------------------------------------------------------------
+    def to_rns(self, coeffs, tidx):
+        """signed integer coefficients (int64 array or list of Python ints) -> [len(tidx)][n] residues"""
+        obj = np.array([int(c) for c in coeffs], dtype=object)
+        out = np.zeros((len(tidx), self.n), dtype=np.uint64)
+        for i, t in enumerate(tidx):
+            out[i] = np.array(obj % int(self.orc.moduli[t]), dtype=np.uint64)
+        return out
+
+    def to_ntt(self, coeffs, tidx):
+        tidx = list(tidx)
+        r = self.to_rns(coeffs, tidx)
+        for i, t in enumerate(tidx):
+            r[i] = self.orc.ntt_fwd(r[i], t)
+        return r
+
+    def _uniform(self, tidx):
+        self._uniform_seed += 1
+        return self.orc.uniform_poly(list(tidx), self._uniform_seed)
+
+    def _error(self):
+        return np.rint(self.rng.normal(0.0, self.sigma, size=self.n)).astype(np.int64)
+
+    def _addmod(self, a, b, tidx):
+        out = np.zeros_like(a)
+        for i, t in enumerate(tidx):
+            q = self.orc.moduli[t]
+            v = a[i] + b[i]
+            out[i] = np.where(v >= q, v - q, v)
+        return out
+
+    def _negmod(self, a, tidx):
+        out = np.zeros_like(a)
+        for i, t in enumerate(tidx):
+            q = self.orc.moduli[t]
+            out[i] = np.where(a[i] == 0, a[i], q - a[i])
+        return out
+
+    # ---- encryption ------------------------------------------------------------------------
+    def encrypt_zero(self, tidx):
+        tidx = list(tidx)
+        a = self._uniform(tidx)
+        e = self.to_ntt(self._error(), tidx)
+        as_ = _pointwise(self.orc, a, self.sk_ntt[tidx], tidx)
+        c0 = self._negmod(self._addmod(as_, e, tidx), tidx)
+        return np.stack([c0, a])
+
+    def encrypt(self, plain_coeffs, size_ql):
+        """Ciphertext [2][size_ql][n] (NTT form) of the integer polynomial plain_coeffs."""
+        tidx = list(range(size_ql))
+        ct = self.encrypt_zero(tidx)
+        ct[0] = self._addmod(ct[0], self.to_ntt(plain_coeffs, tidx), tidx)
+        return ct
+
+    def decrypt(self, ct, size_ql=None):
+        """ct [k][size_ql][n] in NTT form -> list of centred Python ints (mod Q_l)."""
+        ct = np.asarray(ct, dtype=np.uint64)
+        size_ql = ct.shape[1] if size_ql is None else size_ql
+        tidx = list(range(size_ql))
+        acc = ct[0].copy()
+        s_pow = self.sk_ntt[tidx].copy()
+        for i in range(1, ct.shape[0]):
+            acc = self._addmod(acc, _pointwise(self.orc, ct[i], s_pow, tidx), tidx)
+            if i + 1 < ct.shape[0]:
+                s_pow = _pointwise(self.orc, s_pow, self.sk_ntt[tidx], tidx)
+        coeff = np.stack([self.orc.ntt_inv(acc[i], t) for i, t in enumerate(tidx)])
+        return self.crt_compose(coeff, tidx)
+
+    def crt_compose(self, coeff, tidx):
+        qs = [int(self.orc.moduli[t]) for t in tidx]
+        big_q = 1
+        for q in qs:
+            big_q *= q
+        total = np.zeros(self.n, dtype=object)
+        for i, q in enumerate(qs):
+            hat = big_q // q
+            inv = pow(hat % q, -1, q)
+            total = total + (coeff[i].astype(object) * inv % q) * hat
+        total = total % big_q
+        half = big_q // 2
+        return [int(v) - big_q if int(v) > half else int(v) for v in total]
+
+    # ---- key-switching keys ----------------------------------------------------------------
+    def kswitch_key(self, new_key_ntt):
+        """new_key_ntt [size_Q][n] -> list of dnum arrays [2][size_QP][n] (the reference's
+        PhantomRelinKey / one PhantomGaloisKey entry)."""
+        orc = self.orc
+        assert orc.size_Q % orc.size_P == 0, "the reference assumes alpha | size_Q at key level"
+        dnum, alpha = orc.size_Q // orc.size_P, orc.size_P
+        big_p = orc.level_constants(orc.size_Q)["bigP_mod_q"]
+        tidx = list(range(orc.size_QP))
+        evk = []
+        for d in range(dnum):
+            pk = self.encrypt_zero(tidx)
+            for j in range(d * alpha, (d + 1) * alpha):
+                q = int(orc.moduli[j])
+                add = _mulmod_vec(new_key_ntt[j], np.full(self.n, int(big_p[j]), dtype=np.uint64), q)
+                v = pk[0][j] + add
+                pk[0][j] = np.where(v >= orc.moduli[j], v - orc.moduli[j], v)
+            evk.append(np.ascontiguousarray(pk))
+        return evk
+
+    def relin_key(self):
+        tq = list(range(self.orc.size_Q))
+        s2 = _pointwise(self.orc, self.sk_ntt[tq], self.sk_ntt[tq], tq)
+        return self.kswitch_key(s2)
+
+    def galois_coeffs(self, coeffs, elt):
+        """x(X) -> x(X^elt) on signed coefficients (negacyclic: X^n = -1)."""
+        n = self.n
+        out = [0] * n
+        for i, c in enumerate(coeffs):
+            idx = (i * elt) % (2 * n)
+            if idx >= n:
+                out[idx - n] = -int(c)
+            else:
+                out[idx] = int(c)
+        return out
+
+    def galois_key(self, elt):
+        s_g = self.galois_coeffs(self.s, elt)
+        return self.kswitch_key(self.to_ntt(s_g, range(self.orc.size_Q)))
+
+
+def negacyclic_mul(a, b):
+    """Exact product of two integer polynomials modulo X^n + 1 (Python ints)."""
+    n = len(a)
+    a = [int(v) for v in a]
+    b = [int(v) for v in b]
+    # split into a numpy object convolution: O(n^2) is too slow for n = 4096 in pure Python, so
+    # use a float-free Kronecker substitution
+    bound = max(1, max(abs(v) for v in a)) * max(1, max(abs(v) for v in b)) * n
+    bits = bound.bit_length() + 2
+    off = 1 << (bits - 1)
+
+    def pack(v):
+        acc = 0
+        for c in reversed(v):
+            acc = (acc << bits) + c
+        return acc
+
+    prod = pack(a) * pack(b)
+    # unpack signed digits
+    out = [0] * (2 * n)
+    mask = (1 << bits) - 1
+    for i in range(2 * n - 1):
+        d = prod & mask
+        if d >= off:
+            d -= 1 << bits
+        out[i] = d
+        prod = (prod - d) >> bits
+    return [out[i] - out[i + n] for i in range(n)]
