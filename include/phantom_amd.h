@@ -170,6 +170,45 @@ int pha_apply_galois_inplace(pha_context *ctx, size_t chain_index, uint64_t *ct,
 int pha_rescale_to_next(pha_context *ctx, size_t chain_index, const uint64_t *src, size_t cipher_size,
                         uint64_t *dst, pha_stream_t stream);
 
+/* ---- limb-parallel key switch and rescale ---------------------------------
+ * No counterpart in the reference, which is single-GPU: these are the per-rank steps of the
+ * reference's keyswitch_inplace (src/eval_key_switch.cu:91-178) and divide_and_round_q_last_ntt
+ * (src/rns.cu:1157-1181) when the limbs of Q_l u P are partitioned over the GPUs of a node.
+ * A rank owns the Q limbs [q_begin, q_begin+q_count) of Q_l and the special limbs
+ * [p_begin, p_begin+p_count) of P.  Buffers keep the single-GPU layouts (c2 [l][N], t_mod_up
+ * [beta][l+alpha][N], cx [2][l+alpha][N], ct [2][l][N]); each call reads and writes only the owned
+ * limbs, except for the inputs named "gathered".  Between the calls the caller exchanges limbs
+ * (RCCL all-gather / broadcast; phantom-fhe_amd/limb_parallel.py):
+ *   modup_begin  -> all-gather c2_coeff over Q_l            (base conversion needs every input limb)
+ *   modup_finish, key_switch_inner_prod, moddown_begin
+ *                -> all-gather the P limbs of cx (both polys)
+ *   moddown_finish: ct[owned] += key-switched part
+ * Results on the owned limbs are bit-identical to pha_keyswitch_inplace / pha_rescale_to_next. */
+/* c2_coeff[l] = INTT(c2_ntt[l]) * partQlHatInv_l for the owned Q limbs (src/rns_bconv.cu:530-560) */
+int pha_lp_modup_begin(pha_context *ctx, size_t chain_index, const uint64_t *c2_ntt, uint64_t *c2_coeff,
+                       size_t q_begin, size_t q_count, pha_stream_t stream);
+/* owned limbs of every digit of t_mod_up from the gathered c2_coeff (src/rns_bconv.cu:560-628) */
+int pha_lp_modup_finish(pha_context *ctx, size_t chain_index, uint64_t *t_mod_up, const uint64_t *c2_ntt,
+                        const uint64_t *c2_coeff_gathered, size_t q_begin, size_t q_count, size_t p_begin,
+                        size_t p_count, pha_stream_t stream);
+/* owned limbs of cx (src/eval_key_switch.cu:12-88); rlk as in pha_key_switch_inner_prod */
+int pha_lp_key_switch_inner_prod(pha_context *ctx, size_t chain_index, uint64_t *p_cx, const uint64_t *p_t_mod_up,
+                                 const uint64_t *const *rlk, size_t q_begin, size_t q_count, size_t p_begin,
+                                 size_t p_count, pha_stream_t stream);
+/* owned P limbs of both polys of cx: INTT and * PHatInv, in place (src/rns_bconv.cu:776-800) */
+int pha_lp_moddown_begin(pha_context *ctx, size_t chain_index, uint64_t *cx, size_t p_begin, size_t p_count,
+                         pha_stream_t stream);
+/* ct[owned] += (cx - NTT(bconv(gathered P limbs of cx))) * P^-1 (src/rns_bconv.cu:800-828,
+ * src/eval_key_switch.cu:157-177) */
+int pha_lp_moddown_finish(pha_context *ctx, size_t chain_index, uint64_t *ct, uint64_t *cx_gathered, size_t q_begin,
+                          size_t q_count, pha_stream_t stream);
+/* owner of the last limb: last_coeff[p][N] = INTT(src[p][l-1]); broadcast it, then every rank
+ * finishes its owned limbs of dst[cipher_size][l-1][N] (src/rns.cu:1157-1181) */
+int pha_lp_rescale_begin(pha_context *ctx, size_t chain_index, const uint64_t *src, size_t cipher_size,
+                         uint64_t *last_coeff, pha_stream_t stream);
+int pha_lp_rescale_finish(pha_context *ctx, size_t chain_index, const uint64_t *src, const uint64_t *last_coeff,
+                          size_t cipher_size, uint64_t *dst, size_t q_begin, size_t q_count, pha_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,13 @@ SIGNATURES = {
     "pha_multiply_and_relin_inplace": (_int, [_vp, _sz, _vp, _vp, _vp, _vp]),
     "pha_apply_galois_inplace": (_int, [_vp, _sz, _vp, _u32, _vp, _vp]),
     "pha_rescale_to_next": (_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "pha_lp_modup_begin": (_int, [_vp, _sz, _vp, _vp, _sz, _sz, _vp]),
+    "pha_lp_modup_finish": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "pha_lp_key_switch_inner_prod": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "pha_lp_moddown_begin": (_int, [_vp, _sz, _vp, _sz, _sz, _vp]),
+    "pha_lp_moddown_finish": (_int, [_vp, _sz, _vp, _vp, _sz, _sz, _vp]),
+    "pha_lp_rescale_begin": (_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "pha_lp_rescale_finish": (_int, [_vp, _sz, _vp, _vp, _sz, _vp, _sz, _sz, _vp]),
 }
 
 _lib = None
@@ -319,3 +326,29 @@ class PhantomContext:
 
     def rescale_to_next(self, chain_index, src, cipher_size, dst):
         _check(lib().pha_rescale_to_next(self._h, chain_index, _ptr(src), cipher_size, _ptr(dst), _stream()))
+
+    # limb-parallel steps (include/phantom_amd.h "limb-parallel key switch"); w = (q_begin, q_count,
+    # p_begin, p_count), orchestrated by limb_parallel.LimbParallelEvaluator ------------------
+    def lp_modup_begin(self, chain_index, c2_ntt, c2_coeff, w):
+        _check(lib().pha_lp_modup_begin(self._h, chain_index, _ptr(c2_ntt), _ptr(c2_coeff), w[0], w[1], _stream()))
+
+    def lp_modup_finish(self, chain_index, t_mod_up, c2_ntt, c2_coeff, w):
+        _check(lib().pha_lp_modup_finish(self._h, chain_index, _ptr(t_mod_up), _ptr(c2_ntt), _ptr(c2_coeff), w[0], w[1],
+                                         w[2], w[3], _stream()))
+
+    def lp_key_switch_inner_prod(self, chain_index, cx, t_mod_up, evk, w):
+        _check(lib().pha_lp_key_switch_inner_prod(self._h, chain_index, _ptr(cx), _ptr(t_mod_up), evk.ptr, w[0], w[1],
+                                                  w[2], w[3], _stream()))
+
+    def lp_moddown_begin(self, chain_index, cx, w):
+        _check(lib().pha_lp_moddown_begin(self._h, chain_index, _ptr(cx), w[2], w[3], _stream()))
+
+    def lp_moddown_finish(self, chain_index, ct, cx, w):
+        _check(lib().pha_lp_moddown_finish(self._h, chain_index, _ptr(ct), _ptr(cx), w[0], w[1], _stream()))
+
+    def lp_rescale_begin(self, chain_index, src, cipher_size, last_coeff):
+        _check(lib().pha_lp_rescale_begin(self._h, chain_index, _ptr(src), cipher_size, _ptr(last_coeff), _stream()))
+
+    def lp_rescale_finish(self, chain_index, src, last_coeff, cipher_size, dst, w):
+        _check(lib().pha_lp_rescale_finish(self._h, chain_index, _ptr(src), _ptr(last_coeff), cipher_size, _ptr(dst),
+                                           w[0], w[1], _stream()))

@@ -31,6 +31,8 @@ struct LimbMap {
     uint32_t polys;                 // buffers [polys][...] handled by this launch
     uint32_t digit_alpha;           // > 0: poly p is digit p of a modup buffer and skips its own limbs
     uint32_t digit_limit;           //      [p*alpha, min((p+1)*alpha, digit_limit))  (src/rns_bconv.cu:616-620)
+    uint32_t tidx_bias;             // size_P == 0: table index = buffer limb + tidx_bias (a window of the P limbs of
+                                    // a Q_l u P buffer in the limb-parallel key switch)
 };
 
 struct NttTables {
@@ -61,11 +63,15 @@ __device__ __forceinline__ bool resolve_limb(const LimbMap &m, uint32_t poly, ui
         es = poly * m.digit_alpha;
         ee = min(es + m.digit_alpha, m.digit_limit);
     }
+    // only the part of the skipped range that lies inside this launch's window counts
+    es = max(es, m.start);
+    ee = min(ee, m.start + m.count);
     const uint32_t len = ee > es ? ee - es : 0;
     if (li >= m.count - len) return false;
     twr = m.start + li;
     if (len && twr >= es) twr += len;
-    tidx = (m.size_P && twr >= m.start + m.count - m.size_P) ? m.size_QP - (m.start + m.count - twr) : twr;
+    tidx = (m.size_P && twr >= m.start + m.count - m.size_P) ? m.size_QP - (m.start + m.count - twr)
+                                                             : twr + m.tidx_bias;
     return true;
 }
 

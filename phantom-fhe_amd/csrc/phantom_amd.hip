@@ -246,7 +246,7 @@ int make_range(const pha_context *ctx, size_t count, size_t start, size_t size_Q
     r.active = static_cast<uint32_t>(count) - len;
     r.lm = LimbMap{static_cast<uint32_t>(start), static_cast<uint32_t>(count), static_cast<uint32_t>(size_QP),
                    static_cast<uint32_t>(size_P), static_cast<uint32_t>(excl_s), static_cast<uint32_t>(excl_e),
-                   r.active, 1u, 0u, 0u};
+                   r.active, 1u, 0u, 0u, 0u};
     return PHA_OK;
 }
 
@@ -428,7 +428,8 @@ int do_modup(pha_context *ctx, LevelTool *lt, uint64_t *dst, const uint64_t *cks
         PHA_TRY(ntt_backward(ctx, t_cks, cks, 1, 0, r, EPI_NONE, ep, st));
         hipLaunchKernelGGL(modup_single_p_kernel, dim3(static_cast<uint32_t>(n / 256), static_cast<uint32_t>(lt->beta)),
                            dim3(256), 0, st, dst, cks, t_cks, ctx->d_mod.p, static_cast<uint32_t>(size_Ql),
-                           static_cast<uint32_t>(ctx->size_Q), static_cast<uint32_t>(n));
+                           static_cast<uint32_t>(ctx->size_Q), static_cast<uint32_t>(n), 0u,
+                           static_cast<uint32_t>(size_QlP));
         PHA_TRY(check_launch("modup_single_p"));
     } else {
         ep.cst = lt->partHatInv.v.p;
@@ -469,7 +470,7 @@ int do_inner_prod(pha_context *ctx, LevelTool *lt, uint64_t *cx, const uint64_t 
     hipLaunchKernelGGL(key_switch_inner_prod_kernel, dim3(size_QlP * (n / 512)), dim3(256), 0, st, cx, t_mod_up, evks,
                        ctx->d_mod.p, n, static_cast<uint32_t>(ctx->size_QP), size_QlP,
                        static_cast<uint32_t>(ctx->size_Q), static_cast<uint32_t>(lt->size_Ql),
-                       static_cast<uint32_t>(lt->beta));
+                       static_cast<uint32_t>(lt->beta), 0u);
     return check_launch("key_switch_inner_prod");
 }
 
@@ -485,7 +486,7 @@ int do_moddown(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *cx, uint
     if (alpha == 1) {
         PHA_TRY(ntt_backward(ctx, cx, cx, polys, size_QlP * n, rp, EPI_NONE, Epilogue{}, st));
         hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(static_cast<uint32_t>(n / 512), static_cast<uint32_t>(polys)),
-                           dim3(256), 0, st, delta, cp, ctx->d_mod.p, static_cast<uint32_t>(size_Ql),
+                           dim3(256), 0, st, delta, cp, ctx->d_mod.p, 0u, static_cast<uint32_t>(size_Ql),
                            static_cast<uint32_t>(n), size_Ql * n, size_QlP * n);
         PHA_TRY(check_launch("reduce_single_limb"));
     } else {
@@ -530,11 +531,172 @@ int do_rescale(pha_context *ctx, LevelTool *lt, const uint64_t *src, const uint6
     // last_coeff[p * last_stride ...]: INTT'ed last limb of poly p
     const size_t n = ctx->n, size_Ql = lt->size_Ql, next = size_Ql - 1;
     hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(static_cast<uint32_t>(n / 512), static_cast<uint32_t>(cipher_size)),
-                       dim3(256), 0, st, dst, last_coeff, ctx->d_mod.p, static_cast<uint32_t>(next),
+                       dim3(256), 0, st, dst, last_coeff, ctx->d_mod.p, 0u, static_cast<uint32_t>(next),
                        static_cast<uint32_t>(n), next * n, last_stride);
     PHA_TRY(check_launch("reduce_single_limb"));
     NttRange r;
     PHA_TRY(make_range(ctx, next, 0, 0, 0, 0, 0, r));
+    Epilogue ep{};
+    ep.out = dst;
+    ep.sub = src;
+    ep.cst = lt->inv_q_last.v.p;
+    ep.cst_shoup = lt->inv_q_last.s.p;
+    ep.out_poly_stride = next * n;
+    ep.sub_poly_stride = size_Ql * n;
+    return ntt_forward(ctx, dst, cipher_size, next * n, r, EPI_SUB_MUL, ep, st);
+}
+
+// ---- limb-parallel key switch -----------------------------------------------
+// A rank owns the Q limbs [q0, q0+qc) of Q_l and the special limbs [p0, p0+pc) of P; buffers keep
+// the single-GPU layouts and every step touches only the owned limbs.  The exchanges between the
+// steps (all-gather of the scaled coefficient-form c2, all-gather of the scaled coefficient-form
+// P limbs of cx, broadcast of the rescale limb) belong to the caller.
+struct LimbWindow {
+    size_t q0, qc, p0, pc;
+};
+
+int check_window(const pha_context *ctx, const LevelTool *lt, const LimbWindow &w) {
+    if (w.q0 + w.qc > lt->size_Ql || w.p0 + w.pc > ctx->size_P)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "limb window [%zu,+%zu) / [%zu,+%zu) exceeds Q_l (%zu) or P (%zu)", w.q0, w.qc,
+                    w.p0, w.pc, lt->size_Ql, ctx->size_P);
+    return PHA_OK;
+}
+
+// P window of a Q_l u P buffer: buffer limbs [size_Ql + p0, +pc), key-level table indices
+int make_p_window(const pha_context *ctx, const LevelTool *lt, const LimbWindow &w, NttRange &r) {
+    PHA_TRY(make_range(ctx, w.pc, lt->size_Ql + w.p0, 0, 0, 0, 0, r));
+    r.lm.tidx_bias = static_cast<uint32_t>(ctx->size_Q - lt->size_Ql);
+    return PHA_OK;
+}
+
+int lp_modup_begin(pha_context *ctx, LevelTool *lt, const uint64_t *c2_ntt, uint64_t *c2_coeff, const LimbWindow &w,
+                   hipStream_t st) {
+    if (!w.qc) return PHA_OK;
+    NttRange r;
+    PHA_TRY(make_range(ctx, w.qc, w.q0, 0, 0, 0, 0, r));
+    Epilogue ep{};
+    if (ctx->size_P == 1) return ntt_backward(ctx, c2_coeff, c2_ntt, 1, 0, r, EPI_NONE, ep, st);
+    ep.cst = lt->partHatInv.v.p;
+    ep.cst_shoup = lt->partHatInv.s.p;
+    return ntt_backward(ctx, c2_coeff, c2_ntt, 1, 0, r, EPI_SCALE, ep, st);
+}
+
+int lp_modup_finish(pha_context *ctx, LevelTool *lt, uint64_t *t_mod_up, const uint64_t *c2_ntt, const uint64_t *c2_coeff,
+                    const LimbWindow &w, hipStream_t st) {
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, alpha = ctx->size_P, size_QlP = size_Ql + alpha;
+    const size_t win[2][2] = {{w.q0, w.q0 + w.qc}, {size_Ql + w.p0, size_Ql + w.p0 + w.pc}};
+    if (alpha == 1) {
+        for (const auto &jw : win) {
+            if (jw[0] == jw[1]) continue;
+            hipLaunchKernelGGL(modup_single_p_kernel, dim3(static_cast<uint32_t>(n / 256), static_cast<uint32_t>(lt->beta)),
+                               dim3(256), 0, st, t_mod_up, c2_ntt, c2_coeff, ctx->d_mod.p, static_cast<uint32_t>(size_Ql),
+                               static_cast<uint32_t>(ctx->size_Q), static_cast<uint32_t>(n), static_cast<uint32_t>(jw[0]),
+                               static_cast<uint32_t>(jw[1]));
+            PHA_TRY(check_launch("modup_single_p"));
+        }
+    } else {
+        for (size_t d = 0; d < lt->beta; d++) {
+            const size_t s = d * alpha, e = std::min(s + alpha, size_Ql), len = e - s;
+            uint64_t *dst = t_mod_up + d * size_QlP * n;
+            // owned output limbs that are not the digit's own: at most two runs in Q_l, one in P
+            const size_t runs[3][2] = {{w.q0, std::min(w.q0 + w.qc, s)}, {std::max(w.q0, e), w.q0 + w.qc}, {win[1][0], win[1][1]}};
+            for (const auto &run : runs) {
+                if (run[0] >= run[1]) continue;
+                const size_t row = run[0] < s ? run[0] : run[0] - len, cnt = run[1] - run[0];
+                PHA_TRY(launch_bconv(ctx, dst + run[0] * n, c2_coeff + s * n, lt->modup_matrix[d].p + row * len,
+                                     lt->modup_obase_tidx[d].p + row, static_cast<uint32_t>(len), static_cast<uint32_t>(cnt),
+                                     static_cast<uint32_t>(cnt), 0, 1, BconvBatch{}, st));
+            }
+            // the digit's own limbs stay in NTT form (src/rns_bconv.cu:522-528)
+            const size_t a = std::max(w.q0, s), b = std::min(w.q0 + w.qc, e);
+            if (a < b)
+                HIP_TRY(hipMemcpyAsync(dst + a * n, c2_ntt + a * n, (b - a) * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+        }
+    }
+    if (w.qc) {
+        NttRange r;
+        PHA_TRY(make_range(ctx, w.qc, w.q0, 0, 0, 0, 0, r));
+        r.lm.digit_alpha = static_cast<uint32_t>(alpha);
+        r.lm.digit_limit = static_cast<uint32_t>(size_Ql);
+        PHA_TRY(ntt_forward(ctx, t_mod_up, lt->beta, size_QlP * n, r, EPI_NONE, Epilogue{}, st));
+    }
+    if (w.pc) {
+        NttRange r;
+        PHA_TRY(make_p_window(ctx, lt, w, r));
+        PHA_TRY(ntt_forward(ctx, t_mod_up, lt->beta, size_QlP * n, r, EPI_NONE, Epilogue{}, st));
+    }
+    return PHA_OK;
+}
+
+int lp_inner_prod(pha_context *ctx, LevelTool *lt, uint64_t *cx, const uint64_t *t_mod_up, const uint64_t *const *evks,
+                  const LimbWindow &w, hipStream_t st) {
+    const uint32_t n = static_cast<uint32_t>(ctx->n);
+    const uint32_t size_QlP = static_cast<uint32_t>(lt->size_Ql + ctx->size_P);
+    const size_t win[2][2] = {{w.q0, w.qc}, {lt->size_Ql + w.p0, w.pc}};
+    for (const auto &lw : win) {
+        if (!lw[1]) continue;
+        hipLaunchKernelGGL(key_switch_inner_prod_kernel, dim3(static_cast<uint32_t>(lw[1]) * (n / 512)), dim3(256), 0, st, cx,
+                           t_mod_up, evks, ctx->d_mod.p, n, static_cast<uint32_t>(ctx->size_QP), size_QlP,
+                           static_cast<uint32_t>(ctx->size_Q), static_cast<uint32_t>(lt->size_Ql),
+                           static_cast<uint32_t>(lt->beta), static_cast<uint32_t>(lw[0]));
+        PHA_TRY(check_launch("key_switch_inner_prod"));
+    }
+    return PHA_OK;
+}
+
+int lp_moddown_begin(pha_context *ctx, LevelTool *lt, uint64_t *cx, const LimbWindow &w, hipStream_t st) {
+    if (!w.pc) return PHA_OK;
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, size_QlP = size_Ql + ctx->size_P;
+    NttRange rp;
+    PHA_TRY(make_p_window(ctx, lt, w, rp));
+    Epilogue ep{};
+    if (ctx->size_P == 1) return ntt_backward(ctx, cx, cx, 2, size_QlP * n, rp, EPI_NONE, ep, st);
+    ep.cst = lt->PHatInv.v.p - size_Ql;
+    ep.cst_shoup = lt->PHatInv.s.p - size_Ql;
+    return ntt_backward(ctx, cx, cx, 2, size_QlP * n, rp, EPI_SCALE, ep, st);
+}
+
+int lp_moddown_finish(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *cx, const LimbWindow &w, hipStream_t st) {
+    if (!w.qc) return PHA_OK;
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, alpha = ctx->size_P, size_QlP = size_Ql + alpha;
+    uint64_t *delta;
+    PHA_TRY(ensure_workspace(ctx, 2 * size_Ql * n, &delta));
+    uint64_t *cp = cx + size_Ql * n;
+    if (alpha == 1) {
+        hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(static_cast<uint32_t>(n / 512), 2u), dim3(256), 0, st, delta, cp,
+                           ctx->d_mod.p, static_cast<uint32_t>(w.q0), static_cast<uint32_t>(w.q0 + w.qc),
+                           static_cast<uint32_t>(n), size_Ql * n, size_QlP * n);
+        PHA_TRY(check_launch("reduce_single_limb"));
+    } else {
+        BconvBatch bt{size_Ql * n, size_QlP * n, 0, 0, 0, nullptr, 0};
+        PHA_TRY(launch_bconv(ctx, delta + w.q0 * n, cp, lt->moddown_matrix.p + w.q0 * alpha, lt->moddown_obase_tidx.p + w.q0,
+                             static_cast<uint32_t>(alpha), static_cast<uint32_t>(w.qc), static_cast<uint32_t>(w.qc), 0, 2,
+                             bt, st));
+    }
+    NttRange rq;
+    PHA_TRY(make_range(ctx, w.qc, w.q0, 0, 0, 0, 0, rq));
+    Epilogue ep{};
+    ep.out = ct;
+    ep.sub = cx;
+    ep.addend = ct;
+    ep.cst = lt->bigPInv.v.p;
+    ep.cst_shoup = lt->bigPInv.s.p;
+    ep.out_poly_stride = size_Ql * n;
+    ep.sub_poly_stride = size_QlP * n;
+    return ntt_forward(ctx, delta, 2, size_Ql * n, rq, EPI_SUB_MUL_ADD, ep, st);
+}
+
+int lp_rescale_finish(pha_context *ctx, LevelTool *lt, const uint64_t *src, const uint64_t *last_coeff, size_t cipher_size,
+                      uint64_t *dst, const LimbWindow &w, hipStream_t st) {
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, next = size_Ql - 1;
+    const size_t a = std::min(w.q0, next), b = std::min(w.q0 + w.qc, next);
+    if (a >= b) return PHA_OK;
+    hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(static_cast<uint32_t>(n / 512), static_cast<uint32_t>(cipher_size)),
+                       dim3(256), 0, st, dst, last_coeff, ctx->d_mod.p, static_cast<uint32_t>(a), static_cast<uint32_t>(b),
+                       static_cast<uint32_t>(n), next * n, n);
+    PHA_TRY(check_launch("reduce_single_limb"));
+    NttRange r;
+    PHA_TRY(make_range(ctx, b - a, a, 0, 0, 0, 0, r));
     Epilogue ep{};
     ep.out = dst;
     ep.sub = src;
@@ -970,6 +1132,72 @@ int pha_rescale_to_next(pha_context *ctx, size_t chain_index, const uint64_t *sr
         PHA_TRY(ntt_backward(ctx, ws + p * n - (size_Ql - 1) * n, src + p * size_Ql * n, 1, 0, r, EPI_NONE, Epilogue{}, st));
     }
     return do_rescale(ctx, lt, src, ws, n, cipher_size, dst, st);
+}
+
+// ---- limb-parallel entry points (no counterpart in the single-GPU reference) ----
+#define LP_PROLOGUE(ptr_ok)                          \
+    REQUIRE_CTX(ptr_ok);                             \
+    LevelTool *lt;                                   \
+    PHA_TRY(get_level(ctx, chain_index, &lt));       \
+    const LimbWindow w{q_begin, q_count, p_begin, p_count}; \
+    PHA_TRY(check_window(ctx, lt, w))
+
+int pha_lp_modup_begin(pha_context *ctx, size_t chain_index, const uint64_t *c2_ntt, uint64_t *c2_coeff, size_t q_begin,
+                       size_t q_count, pha_stream_t stream) {
+    const size_t p_begin = 0, p_count = 0;
+    LP_PROLOGUE(c2_ntt && c2_coeff);
+    return lp_modup_begin(ctx, lt, c2_ntt, c2_coeff, w, as_stream(stream));
+}
+
+int pha_lp_modup_finish(pha_context *ctx, size_t chain_index, uint64_t *t_mod_up, const uint64_t *c2_ntt,
+                        const uint64_t *c2_coeff, size_t q_begin, size_t q_count, size_t p_begin, size_t p_count,
+                        pha_stream_t stream) {
+    LP_PROLOGUE(t_mod_up && c2_ntt && c2_coeff);
+    return lp_modup_finish(ctx, lt, t_mod_up, c2_ntt, c2_coeff, w, as_stream(stream));
+}
+
+int pha_lp_key_switch_inner_prod(pha_context *ctx, size_t chain_index, uint64_t *p_cx, const uint64_t *p_t_mod_up,
+                                 const uint64_t *const *rlk, size_t q_begin, size_t q_count, size_t p_begin,
+                                 size_t p_count, pha_stream_t stream) {
+    LP_PROLOGUE(p_cx && p_t_mod_up && rlk);
+    return lp_inner_prod(ctx, lt, p_cx, p_t_mod_up, rlk, w, as_stream(stream));
+}
+
+int pha_lp_moddown_begin(pha_context *ctx, size_t chain_index, uint64_t *cx, size_t p_begin, size_t p_count,
+                         pha_stream_t stream) {
+    const size_t q_begin = 0, q_count = 0;
+    LP_PROLOGUE(cx);
+    return lp_moddown_begin(ctx, lt, cx, w, as_stream(stream));
+}
+
+int pha_lp_moddown_finish(pha_context *ctx, size_t chain_index, uint64_t *ct, uint64_t *cx, size_t q_begin, size_t q_count,
+                          pha_stream_t stream) {
+    const size_t p_begin = 0, p_count = 0;
+    LP_PROLOGUE(ct && cx);
+    return lp_moddown_finish(ctx, lt, ct, cx, w, as_stream(stream));
+}
+
+int pha_lp_rescale_begin(pha_context *ctx, size_t chain_index, const uint64_t *src, size_t cipher_size,
+                         uint64_t *last_coeff, pha_stream_t stream) {
+    REQUIRE_CTX(src && last_coeff);
+    LevelTool *lt;
+    PHA_TRY(get_level(ctx, chain_index, &lt));
+    if (lt->size_Ql < 2) return fail(PHA_ERR_INVALID_ARGUMENT, "end of modulus switching chain reached");
+    const size_t n = ctx->n, size_Ql = lt->size_Ql;
+    NttRange r;
+    PHA_TRY(make_range(ctx, 1, size_Ql - 1, 0, 0, 0, 0, r));
+    for (size_t p = 0; p < cipher_size; p++)
+        PHA_TRY(ntt_backward(ctx, last_coeff + p * n - (size_Ql - 1) * n, src + p * size_Ql * n, 1, 0, r, EPI_NONE,
+                             Epilogue{}, as_stream(stream)));
+    return PHA_OK;
+}
+
+int pha_lp_rescale_finish(pha_context *ctx, size_t chain_index, const uint64_t *src, const uint64_t *last_coeff,
+                          size_t cipher_size, uint64_t *dst, size_t q_begin, size_t q_count, pha_stream_t stream) {
+    const size_t p_begin = 0, p_count = 0;
+    LP_PROLOGUE(src && last_coeff && dst);
+    if (lt->size_Ql < 2) return fail(PHA_ERR_INVALID_ARGUMENT, "end of modulus switching chain reached");
+    return lp_rescale_finish(ctx, lt, src, last_coeff, cipher_size, dst, w, as_stream(stream));
 }
 
 }  // extern "C"

@@ -117,14 +117,15 @@ __global__ __launch_bounds__(256) void bconv_matmul_generic_kernel(uint64_t *dst
 // NTT-form limb for j == d and (coeff mod p_j) otherwise.
 __global__ __launch_bounds__(256) void modup_single_p_kernel(uint64_t *dst, const uint64_t *cks_ntt,
                                                              const uint64_t *cks_coeff, const DModulus *mod,
-                                                             uint32_t size_Ql, uint32_t size_Q, uint32_t n) {
+                                                             uint32_t size_Ql, uint32_t size_Q, uint32_t n,
+                                                             uint32_t j_begin, uint32_t j_end) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     const uint32_t d = blockIdx.y;
     const uint32_t size_QlP = size_Ql + 1;
     const uint64_t coeff = cks_coeff[static_cast<size_t>(d) * n + k];
     const uint64_t in_prime = mod[d].value;
     uint64_t *o = dst + static_cast<size_t>(d) * size_QlP * n + k;
-    for (uint32_t j = 0; j < size_QlP; j++) {
+    for (uint32_t j = j_begin; j < j_end; j++) {  // output limbs [j_begin, j_end) of [0, size_QlP)
         uint64_t v;
         if (j == d) {
             v = cks_ntt[static_cast<size_t>(d) * n + k];
@@ -136,14 +137,15 @@ __global__ __launch_bounds__(256) void modup_single_p_kernel(uint64_t *dst, cons
     }
 }
 
-// dst[j][k] = src[k] mod q_j for j < limbs (src/rns_bconv.cu:691-707, src/rns.cu:1125-1136)
+// dst[j][k] = src[k] mod q_j for j in [j_begin, j_end) (src/rns_bconv.cu:691-707, src/rns.cu:1125-1136)
 __global__ __launch_bounds__(256) void reduce_single_limb_kernel(uint64_t *dst, const uint64_t *src,
-                                                                 const DModulus *mod, uint32_t limbs, uint32_t n,
-                                                                 size_t dst_poly_stride, size_t src_poly_stride) {
+                                                                 const DModulus *mod, uint32_t j_begin, uint32_t j_end,
+                                                                 uint32_t n, size_t dst_poly_stride,
+                                                                 size_t src_poly_stride) {
     const uint32_t k = (blockIdx.x * 256 + threadIdx.x) * 2;
     const ulonglong2 c = *reinterpret_cast<const ulonglong2 *>(src + blockIdx.y * src_poly_stride + k);
     uint64_t *o = dst + blockIdx.y * dst_poly_stride + k;
-    for (uint32_t j = 0; j < limbs; j++) {
+    for (uint32_t j = j_begin; j < j_end; j++) {
         const DModulus m = mod[j];
         ulonglong2 v;
         v.x = barrett64(c.x, m.value, m.ratio1);
@@ -159,9 +161,10 @@ __global__ __launch_bounds__(256) void reduce_single_limb_kernel(uint64_t *dst, 
 __global__ __launch_bounds__(256) void key_switch_inner_prod_kernel(uint64_t *dst, const uint64_t *t_mod_up,
                                                                     const uint64_t *const *evks, const DModulus *mod,
                                                                     uint32_t n, uint32_t size_QP, uint32_t size_QlP,
-                                                                    uint32_t size_Q, uint32_t size_Ql, uint32_t beta) {
+                                                                    uint32_t size_Q, uint32_t size_Ql, uint32_t beta,
+                                                                    uint32_t limb0) {
     const uint32_t per_limb = n / 512;
-    const uint32_t nid = blockIdx.x / per_limb;
+    const uint32_t nid = limb0 + blockIdx.x / per_limb;  // limbs [limb0, limb0 + gridDim.x / per_limb)
     const uint32_t k = ((blockIdx.x % per_limb) * 256 + threadIdx.x) * 2;
     const uint32_t twr = nid >= size_Ql ? size_Q + (nid - size_Ql) : nid;
     const DModulus m = mod[twr];

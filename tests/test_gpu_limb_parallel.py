@@ -1,0 +1,140 @@
+"""Limb-parallel key switch / rotation / rescale on one GPU: `world` simulated
+ranks (threads, each with its own context and buffers, exchanging through ThreadComm) must
+reproduce the oracle's single-device result bit for bit on the limbs they own, reading nothing
+outside their windows except what the exchanges deliver."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, LOG_N = 4096, 12
+POISON = np.uint64(0x5EEDBADC0FFEE123)
+
+
+def _run_ranks(world, body):
+    from phantom_fhe_amd.limb_parallel import ThreadComm
+    shared = ThreadComm.Shared(world)
+    errors, results = [], [None] * world
+
+    def target(rank):
+        try:
+            results[rank] = body(rank, ThreadComm(shared, rank))
+        except BaseException as e:  # noqa: BLE001 - reported below
+            errors.append((rank, e))
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=target, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    real = [e for e in errors if not isinstance(e[1], threading.BrokenBarrierError)] or errors
+    if real:
+        raise real[0][1]
+    return results
+
+
+def _owned_only(a, begin, count, axis_limb):
+    """copy of `a` with every limb outside [begin, begin+count) poisoned"""
+    out = np.full_like(a, POISON)
+    sl = [slice(None)] * a.ndim
+    sl[axis_limb] = slice(begin, begin + count)
+    out[tuple(sl)] = a[tuple(sl)]
+    return out
+
+
+def _uniform_evk(o, seed):
+    beta_max = -(-o.size_Q // o.size_P)
+    return [np.stack([o.uniform_poly(list(range(o.size_QP)), seed + 2 * d),
+                      o.uniform_poly(list(range(o.size_QP)), seed + 2 * d + 1)]) for d in range(beta_max)]
+
+
+@pytest.mark.parametrize("world,size_p,chain_index", [(2, 2, 1), (3, 2, 2), (8, 2, 1), (4, 1, 1), (3, 3, 1), (2, 3, 3),
+                                                      (5, 1, 4)])
+def test_keyswitch_rotation_rescale(gpu, pha, orc, world, size_p, chain_index):
+    from phantom_fhe_amd.limb_parallel import LimbParallelEvaluator, limb_window
+    mods = orc.coeff_modulus_create(N, [45] * 6 + [55] * size_p)
+    o = orc.Oracle(LOG_N, mods, size_p)
+    size_ql = o.size_Q - (chain_index - 1)
+    lim = list(range(size_ql))
+    ct = np.stack([o.uniform_poly(lim, 31), o.uniform_poly(lim, 32)])
+    c2 = o.uniform_poly(lim, 33)
+    evk_h = _uniform_evk(o, 200)
+    elt = orc.galois_elt_from_step(LOG_N, 3)
+
+    exp_ks = ct.copy()
+    o.keyswitch_inplace(size_ql, exp_ks, c2, evk_h)
+    rot_c1 = o.apply_galois_ntt(ct[1], elt)
+    exp_rot = np.stack([o.apply_galois_ntt(ct[0], elt), np.zeros_like(rot_c1)])
+    o.keyswitch_inplace(size_ql, exp_rot, rot_c1, evk_h)
+    exp_rs = o.divide_and_round_q_last_ntt(size_ql, ct, 2) if size_ql > 1 else None
+
+    # the windows tile Q_l and P exactly
+    wins = [limb_window(size_ql, size_p, world, r) for r in range(world)]
+    assert sorted(l for q0, qc, _, _ in wins for l in range(q0, q0 + qc)) == lim
+    assert sorted(l for _, _, p0, pc in wins for l in range(p0, p0 + pc)) == list(range(size_p))
+
+    def body(rank, comm):
+        ctx = pha.PhantomContext(LOG_N, mods, size_p)
+        ev = LimbParallelEvaluator(ctx, comm)
+        q0, qc, _, _ = ev.windows(chain_index)[rank]
+        evk = pha.EvalKey([pha.to_device(k) for k in evk_h])
+        out = {}
+        d_ct = pha.to_device(_owned_only(ct, q0, qc, 1))
+        ev.keyswitch_inplace(chain_index, d_ct, pha.to_device(_owned_only(c2, q0, qc, 0)), evk)
+        out["ks_owned"] = pha.to_host(d_ct)[:, q0:q0 + qc].copy()
+        ev.gather_limbs(chain_index, [d_ct[0], d_ct[1]])
+        out["ks_full"] = pha.to_host(d_ct)
+
+        d_rot = pha.to_device(_owned_only(ct, q0, qc, 1))
+        ev.apply_galois_inplace(chain_index, d_rot, elt, evk)
+        out["rot_owned"] = pha.to_host(d_rot)[:, q0:q0 + qc].copy()
+
+        if size_ql > 1:
+            d_dst = pha.to_device(np.full((2, size_ql - 1, N), POISON, dtype=np.uint64))
+            ev.rescale_to_next(chain_index, pha.to_device(_owned_only(ct, q0, qc, 1)), 2, d_dst)
+            ev.gather_limbs(chain_index, [d_dst[0], d_dst[1]], size_ql - 1)
+            out["rs_full"] = pha.to_host(d_dst)
+        gpu.cuda.synchronize()
+        ctx.close()
+        return out
+
+    results = _run_ranks(world, body)
+    for rank, res in enumerate(results):
+        q0, qc, _, _ = wins[rank]
+        assert (res["ks_owned"] == exp_ks[:, q0:q0 + qc]).all(), f"rank {rank} key switch"
+        assert (res["ks_full"] == exp_ks).all(), f"rank {rank} gathered key switch"
+        assert (res["rot_owned"] == exp_rot[:, q0:q0 + qc]).all(), f"rank {rank} rotation"
+        if exp_rs is not None:
+            assert (res["rs_full"] == exp_rs).all(), f"rank {rank} rescale"
+
+
+def test_window_validation(gpu, pha, orc):
+    mods = orc.coeff_modulus_create(N, [45] * 4 + [55] * 2)
+    ctx = pha.PhantomContext(LOG_N, mods, 2)
+    d = pha.to_device(np.zeros((2, 6, N), dtype=np.uint64))
+    with pytest.raises(pha.PhantomError) as e:
+        ctx.lp_moddown_finish(1, d, d, (3, 2, 0, 0))  # Q window [3,5) exceeds the 4 Q limbs
+    assert e.value.code == pha.PHA_ERR_INVALID_ARGUMENT
+    with pytest.raises(pha.PhantomError):
+        ctx.lp_moddown_begin(1, d, (0, 0, 1, 2))  # P window [1,3) exceeds alpha = 2
+    ctx.close()
+
+
+@pytest.mark.parametrize("backend,nproc", [("gloo", 2), ("nccl", 1)])
+def test_torch_distributed_ranks(gpu, backend, nproc):
+    """The same path through torch.distributed: two processes sharing this GPU over gloo (host-staged
+    exchange), and the RCCL code path with the one rank a one-GPU box allows."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+                          "--master-addr", "127.0.0.1", "--master-port", "29641", os.path.join(root, "tools", "lp_keyswitch.py"),
+                          "--backend", backend, "--log-n", "12", "--q-limbs", "5", "--p-limbs", "2", "--q-bits", "45",
+                          "--p-bits", "55", "--check"], capture_output=True, text=True, timeout=170, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert out.stdout.count("ok rank") == nproc
