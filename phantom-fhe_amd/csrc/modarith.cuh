@@ -162,9 +162,11 @@ __device__ __forceinline__ void gs_butterfly4(uint64_t &x, uint64_t &y, const tw
 template <bool NARROW>
 struct IntField {
     using elem = uint64_t;
-    using twt = tw_t;
+    using twt = tw_t;  // twiddle as the butterflies use it
+    using twl = tw_t;  // twiddle as the tables store it
     LazyMod m;
     __device__ __forceinline__ explicit IntField(const DModulus &mod) : m(mod.value) {}
+    __device__ __forceinline__ twt prep(const twl &w) const { return w; }
     __device__ __forceinline__ elem from_u64(uint64_t v) const { return v; }
     __device__ __forceinline__ uint64_t to_u64(elem v) const { return v; }
     __device__ __forceinline__ static uint64_t raw(elem v) { return v; }
@@ -204,10 +206,16 @@ struct IntField {
 //   mulmod(y, {w, w/q}), |y| <= 2^52:  h = fl(y*w), l = y*w - h (one fma), c = rint(y * (w/q));
 //       |y*w/q - c| <= 1/2 + |y| 2^-52  =>  t = (h - c*q) + l = y*w - c*q,  |t| <= 1.5q + 1
 //   reduce(x): x - rint(x/q)*q, |result| <= q/2 + 1
+// The tables store only w (8 bytes per twiddle: half the table traffic of the integer path's
+// {w, Shoup companion}); w/q is formed as w * fl(1/q) when the twiddle is loaded.  With that
+// product's extra rounding the quotient estimate is off by at most 1/2 + 1.5 |y| 2^-52, so
+//   |t| <= (1/2 + 1.5 |y| / 2^52) q   (< 2q for |y| <= 4q <= 2^52).
 struct FpField {
     using elem = double;
-    using twt = double2;  // {w, w/q}
+    using twt = double2;  // {w, ~w/q}
+    using twl = double;   // stored form
     double q, qinv;
+    __device__ __forceinline__ twt prep(twl w) const { return twt{w, w * qinv}; }
     __device__ __forceinline__ explicit FpField(const DModulus &mod)
         : q(static_cast<double>(static_cast<int64_t>(mod.value))), qinv(1.0 / q) {}
     // 0 <= v < 2^52: splice into the mantissa of 2^52 and subtract
@@ -240,9 +248,11 @@ struct FpField {
         const double r = reduce(v);
         return r < 0.0 ? r + q : r;
     }
-    // Forward butterfly.  Even stage: x is reduced (|u| <= q/2+1), |y| <= 4q -> outputs <= 2q+2;
-    // odd stage: inputs <= 2q+2 -> outputs <= 3.5q+3 < 4q <= 2^52.  API inputs may be lazy up to
-    // 4q like the reference's (they enter an even stage).
+    // Forward butterfly, bounds in units of q.  Even stage: x is reduced (<= 1/2), |y| <= a <= 4:
+    // t <= 1/2 + 0.375 a, outputs b <= 1 + 0.375 a <= 2.5; odd stage (no reduction): t <= 1/2 +
+    // 0.375 b, outputs <= 1/2 + 1.375 b = 1.875 + 0.516 a <= 3.94 -> the range contracts to a
+    // fixed point of 3.87 q < 4q <= 2^52.  API inputs may be lazy up to 4q like the reference's
+    // (they enter an even stage).
     template <int PAR>
     __device__ __forceinline__ void ct(elem &x, elem &y, const twt &w) const {
         const double t = mulmod(y, w);
@@ -251,7 +261,8 @@ struct FpField {
         y = u - t;
     }
     __device__ __forceinline__ elem canon_fwd(elem v) const { return canon(v); }
-    // Inverse butterfly: inputs |.| <= q+2 -> sum reduced to <= q/2+1, product <= q+1
+    // Inverse butterfly: inputs |.| <= 2q -> |d| <= 4q <= 2^52, sum reduced to <= q/2+1, product
+    // <= (1/2 + 1.5 * 4q / 2^52) q <= 2q
     __device__ __forceinline__ void gs(elem &x, elem &y, const twt &w) const {
         const double d = x - y;
         x = reduce(x + y);

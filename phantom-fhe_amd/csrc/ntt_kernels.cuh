@@ -42,7 +42,8 @@ struct NttTables {
     const uint64_t *n_inv, *n_inv_shoup;  // [size_QP]
     uint32_t log_n;
     uint32_t twD_stride;   // records per limb in twD
-    uint32_t fp64;         // limbs with q < 2^50 hold {double w, double w/q} records and run on FpField
+    uint32_t fp64;         // limbs with q < 2^50 run on FpField; their table regions hold one double w per
+                           // twiddle (8-byte records in the same order, first half of the region)
 };
 
 // out[l][e] = (sub[l][e] - x) * cst[l] (+ addend[l][e])   or   x * cst[l]
@@ -114,7 +115,7 @@ __device__ __forceinline__ void ct_radix(typename F::elem (&x)[1 << R], const Tw
         const int half = 1 << (R - 1 - s);
 #pragma unroll
         for (int jb = 0; jb < (1 << s); jb++) {
-            const typename F::twt w = tw(s, jb);
+            const typename F::twt w = f.prep(tw(s, jb));
 #pragma unroll
             for (int i = 0; i < half; i++) {
                 typename F::elem &a = x[jb * 2 * half + i], &b = x[jb * 2 * half + half + i];
@@ -137,14 +138,14 @@ __device__ __forceinline__ void gs_radix(typename F::elem (&x)[1 << R], const Tw
         const int half = 1 << (R - 1 - s);
 #pragma unroll
         for (int jb = 0; jb < (1 << s); jb++) {
-            const typename F::twt w = tw(s, jb);
+            const typename F::twt w = f.prep(tw(s, jb));
 #pragma unroll
             for (int i = 0; i < half; i++) f.gs(x[jb * 2 * half + i], x[jb * 2 * half + half + i], w);
         }
     }
     if (LAST) {
         const int half = 1 << (R - 1);
-        const typename F::twt w = tw(0, 0);
+        const typename F::twt w = f.prep(tw(0, 0));
 #pragma unroll
         for (int i = 0; i < half; i++) f.gs_last(x[i], x[half + i], w, n_inv);
     }
@@ -175,7 +176,7 @@ __device__ __forceinline__ bool use_fp64(const NttTables &T, const DModulus &mod
 template <int S1, int RA, class F>
 __device__ __forceinline__ void fntt_col_body(uint64_t *lds, uint64_t *base, const tw_t *tw_raw, uint32_t n2, const F &f) {
     constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
-    using TW = typename F::twt;
+    using TW = typename F::twl;
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
     const uint32_t t = threadIdx.x;
 #pragma unroll
@@ -229,7 +230,7 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, uint64_t *base, con
                                               const uint64_t *sub, const uint64_t *addend, uint64_t cst,
                                               uint64_t cst_shoup) {
     constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
-    using TW = typename F::twt;
+    using TW = typename F::twl;
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
     const uint32_t t = threadIdx.x;
 #pragma unroll
@@ -258,7 +259,7 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, uint64_t *base, con
     }
     __syncthreads();
 
-    const TW c = f.make_cst(cst, cst_shoup);
+    const typename F::twt c = f.make_cst(cst, cst_shoup);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint32_t e = (i * kThreads + t) * 2;
@@ -323,10 +324,10 @@ template <int S2, int RA, class F>
 __device__ __forceinline__ void intt_row_body(uint64_t *lds, uint64_t *dst, const uint64_t *src, const tw_t *tw_raw,
                                               const tw_t *twd_raw, uint32_t n1, uint32_t ti, const F &f) {
     constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
-    using TW = typename F::twt;
+    using TW = typename F::twl;
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
     const uint32_t t = threadIdx.x;
-    const TW unused{};
+    const typename F::twt unused{};
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint32_t e = (i * kThreads + t) * 2;
@@ -388,10 +389,10 @@ template <int S1, int RA, int EPI, class F>
 __device__ __forceinline__ void intt_col_body(uint64_t *lds, uint64_t *base, const tw_t *tw_raw, uint32_t n2, const F &f,
                                               uint64_t n_inv, uint64_t n_inv_shoup, uint64_t cst, uint64_t cst_shoup) {
     constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
-    using TW = typename F::twt;
+    using TW = typename F::twl;
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
     const uint32_t t = threadIdx.x;
-    const TW ninv = f.make_cst(n_inv, n_inv_shoup);
+    const typename F::twt ninv = f.make_cst(n_inv, n_inv_shoup);
 #pragma unroll
     for (int g = 0; g < GB; g++) {
         const uint32_t gid = t + kThreads * g, c = gid % C, r_hi = gid / C;
@@ -403,7 +404,7 @@ __device__ __forceinline__ void intt_col_body(uint64_t *lds, uint64_t *base, con
         for (int j = 0; j < (1 << RB); j++) lds[lds_col<C, RB>((r_hi << RB) | j, c)] = F::raw(x[j]);
     }
     __syncthreads();
-    const TW c_scale = f.make_cst(cst, cst_shoup);
+    const typename F::twt c_scale = f.make_cst(cst, cst_shoup);
 #pragma unroll
     for (int g = 0; g < GA; g++) {
         const uint32_t gid = t + kThreads * g, c = gid % C, r_lo = gid / C;

@@ -173,15 +173,13 @@ void last_pass_order(const tw_t *canon, size_t n, int rb, tw_t *dst) {
     }
 }
 
-// {w, w_shoup} -> {double(w), double(w) / double(q)} for the limbs that run on FpField (same
-// 16-byte records, same order)
-void to_fp64_records(tw_t *rec, size_t count, uint64_t q) {
-    const double dq = static_cast<double>(q);
-    for (size_t i = 0; i < count; i++) {
-        const double w = static_cast<double>(rec[i].x), wq = w / dq;
-        memcpy(&rec[i].x, &w, sizeof(double));
-        memcpy(&rec[i].y, &wq, sizeof(double));
-    }
+// {w, w_shoup} records -> one double(w) per twiddle, same order, packed into the first half of
+// the limb's region (limbs that run on FpField)
+void to_fp64_records(tw_t *rec, size_t count) {
+    std::vector<double> w(count);
+    for (size_t i = 0; i < count; i++) w[i] = static_cast<double>(rec[i].x);
+    memset(rec, 0, count * sizeof(tw_t));
+    memcpy(rec, w.data(), count * sizeof(double));
 }
 
 int upload_tables(pha_context *ctx) {
@@ -199,10 +197,10 @@ int upload_tables(pha_context *ctx) {
         last_pass_order(tw.data() + l * n, n, rb, twD.data() + l * stride);
         last_pass_order(itw.data() + l * n, n, rb, itwD.data() + l * stride);
         if (ctx->limb_is_fp64(l)) {
-            to_fp64_records(tw.data() + l * n, n, t.q);
-            to_fp64_records(itw.data() + l * n, n, t.q);
-            to_fp64_records(twD.data() + l * stride, stride, t.q);
-            to_fp64_records(itwD.data() + l * stride, stride, t.q);
+            to_fp64_records(tw.data() + l * n, n);
+            to_fp64_records(itw.data() + l * n, n);
+            to_fp64_records(twD.data() + l * stride, stride);
+            to_fp64_records(itwD.data() + l * stride, stride);
         }
         mods[l] = DModulus{t.q, t.ratio[0], t.ratio[1]};
         ninv[l] = t.n_inv;
@@ -861,14 +859,12 @@ int pha_context_get_table(const pha_context *ctx, size_t limb, int which, uint64
     std::vector<tw_t> h(ctx->n);
     HIP_TRY(hipMemcpy(h.data(), src, ctx->n * sizeof(tw_t), hipMemcpyDeviceToHost));
     if (ctx->limb_is_fp64(limb)) {
-        // FP64 limbs keep {double w, double w/q}: the value comes back from the device, its Shoup
+        // FP64 limbs keep one double per twiddle: the value comes back from the device, its Shoup
         // companion (unused by the kernels on such a limb) from the host tables
         const LimbTables &t = ctx->host_tables[limb];
-        for (size_t i = 0; i < ctx->n; i++) {
-            double w;
-            memcpy(&w, &h[i].x, sizeof(double));
-            out_host[i] = (which & 1) ? (which == 1 ? t.tw_shoup[i] : t.itw_shoup[i]) : static_cast<uint64_t>(w);
-        }
+        const double *w = reinterpret_cast<const double *>(h.data());
+        for (size_t i = 0; i < ctx->n; i++)
+            out_host[i] = (which & 1) ? (which == 1 ? t.tw_shoup[i] : t.itw_shoup[i]) : static_cast<uint64_t>(w[i]);
         return PHA_OK;
     }
     for (size_t i = 0; i < ctx->n; i++) out_host[i] = (which & 1) ? h[i].y : h[i].x;
