@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""BASELINE config 4: CKKS rotate (apply_galois + key switch) on 64 independent ciphertexts,
+N=2^16, 36 Q limbs + 12 special primes, dealt to the ranks of one node (no data-path collective;
+`scaling: strong` — the 64 ciphertexts are the whole job).
+
+    python tools/bench_rotate64.py                       # one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node G --master-addr 127.0.0.1 tools/bench_rotate64.py
+"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import bench
+import phantom_fhe_amd as pha
+
+N, SIZE_Q, SIZE_P, TOTAL = 65536, 36, 12, 64
+
+
+def main():
+    steps = int(os.environ.get("STEPS", "3"))
+    rank, world, local_rank, dist = bench.dist_setup("nccl")
+    torch.cuda.set_device(local_rank)
+    mods = pha.coeff_modulus_create(N, [60] + [50] * (SIZE_Q - 1) + [60] * SIZE_P)
+    ctx = pha.PhantomContext(16, mods, SIZE_P)
+    lo, hi = bench.shard_units(TOTAL, world, rank)
+    g = torch.Generator(device="cuda").manual_seed(100 + rank)
+    small = int(mods.min())
+    cts = [torch.randint(0, small, (2, SIZE_Q, N), dtype=torch.int64, device="cuda", generator=g) for _ in range(lo, hi)]
+    evk = pha.EvalKey([torch.randint(0, small, (2, SIZE_Q + SIZE_P, N), dtype=torch.int64, device="cuda", generator=g)
+                       for _ in range(SIZE_Q // SIZE_P)])
+    elt = pha.galois_elt_from_step(16, 1)
+
+    def step():
+        for ct in cts:
+            ctx.apply_galois_inplace(1, ct, elt, evk)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    el = bench.max_over_ranks(time.perf_counter() - t0, dist, "cuda")
+    if rank == 0:
+        print(json.dumps({"metric": "CKKS rotate, 64 independent ciphertexts (N=2^16, 36+12 limbs, dnum=3)",
+                          "value": TOTAL * steps / el, "unit": "ciphertexts/s", "ms_per_64": 1e3 * el / steps,
+                          "n_gpus": world, "steps": steps, "scaling": "strong", "data": "synthetic"}), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
