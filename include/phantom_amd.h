@@ -209,6 +209,34 @@ int pha_lp_rescale_begin(pha_context *ctx, size_t chain_index, const uint64_t *s
 int pha_lp_rescale_finish(pha_context *ctx, size_t chain_index, const uint64_t *src, const uint64_t *last_coeff,
                           size_t cipher_size, uint64_t *dst, size_t q_begin, size_t q_count, pha_stream_t stream);
 
+/* ---- key generation, symmetric encryption, decryption --------------------
+ * PhantomSecretKey's methods (include/secretkey.h:150-290, src/secretkey.cu) over caller-owned
+ * buffers.  Distributions are the reference's (src/prng.cu: ternary, centred binomial, uniform by
+ * rejection); the generator is seeded and random-access (csrc/keygen_kernels.cuh) where the
+ * reference seeds from std::random_device, so results are reproducible from the seeds.
+ * chain_index 0 is the key level (all of Q u P), i >= 1 the first size_Q-(i-1) limbs of Q. */
+/* gen_secretkey (src/secretkey.cu:368-440): sk[size_QP][N], ternary, NTT form */
+int pha_gen_secretkey(pha_context *ctx, uint64_t seed, uint64_t *sk, pha_stream_t stream);
+/* encrypt_zero_symmetric (src/secretkey.cu:207-263, NTT form): ct[2][l][N] = (-(a*s+e), a) */
+int pha_encrypt_zero_symmetric(pha_context *ctx, const uint64_t *sk, size_t chain_index, uint64_t seed_a,
+                               uint64_t seed_e, uint64_t *ct, pha_stream_t stream);
+/* encrypt_symmetric (src/secretkey.cu:548-582): c0 += plain, plain[l][N] in NTT form */
+int pha_encrypt_symmetric(pha_context *ctx, const uint64_t *sk, const uint64_t *plain, size_t chain_index,
+                          uint64_t seed_a, uint64_t seed_e, uint64_t *ct, pha_stream_t stream);
+/* ckks_decrypt (src/secretkey.cu:584-624): plain[l][N] = sum_i ct_i * s^i, NTT form */
+int pha_ckks_decrypt(pha_context *ctx, const uint64_t *sk, const uint64_t *ct, size_t cipher_size, size_t chain_index,
+                     uint64_t *plain, pha_stream_t stream);
+/* generate_one_kswitch_key (src/secretkey.cu:265-310, src/polymath.cu:323-343): evks_host is a
+ * HOST array of dnum = size_Q/size_P device buffers [2][size_QP][N]; new_key[size_Q][N] */
+int pha_generate_one_kswitch_key(pha_context *ctx, const uint64_t *sk, const uint64_t *new_key, uint64_t seed,
+                                 uint64_t *const *evks_host, pha_stream_t stream);
+/* gen_relinkey (src/secretkey.cu:452-477): new_key = s^2 */
+int pha_gen_relinkey(pha_context *ctx, const uint64_t *sk, uint64_t seed, uint64_t *const *evks_host,
+                     pha_stream_t stream);
+/* one entry of create_galois_keys (src/secretkey.cu:479-521): new_key = s(X^galois_elt) */
+int pha_gen_galois_key(pha_context *ctx, const uint64_t *sk, uint32_t galois_elt, uint64_t seed,
+                       uint64_t *const *evks_host, pha_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

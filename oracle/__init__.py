@@ -70,6 +70,18 @@ def lib():
             "orc_apply_galois_coeff": (None, [_vp, _u64p, _sz, _u32, _u64p]),
             "orc_tensor_prod_2x2": (None, [_vp, _u64p, _u64p, _sz, _u64p]),
             "orc_tensor_square_2x2": (None, [_vp, _u64p, _sz, _u64p]),
+            "orc_pointwise_mul": (None, [_vp, _u64p, _u64p, _u64p, _sz, ctypes.POINTER(_sz)]),
+            "orc_rnd_at": (_u64, [_u64, _u64]),
+            "orc_sample_ternary": (None, [_vp, _u64p, _sz, ctypes.POINTER(_sz), _u64]),
+            "orc_sample_error": (None, [_vp, _u64p, _sz, ctypes.POINTER(_sz), _u64]),
+            "orc_sample_uniform": (None, [_vp, _u64p, _sz, ctypes.POINTER(_sz), _u64]),
+            "orc_gen_secretkey": (None, [_vp, _u64, _u64p]),
+            "orc_encrypt_zero_symmetric": (None, [_vp, _u64p, _sz, _u64, _u64, _u64p]),
+            "orc_encrypt_symmetric": (None, [_vp, _u64p, _u64p, _sz, _u64, _u64, _u64p]),
+            "orc_ckks_decrypt": (None, [_vp, _u64p, _u64p, _sz, _sz, _u64p]),
+            "orc_generate_one_kswitch_key": (None, [_vp, _u64p, _u64p, _u64, ctypes.POINTER(_u64p)]),
+            "orc_gen_relinkey": (None, [_vp, _u64p, _u64, ctypes.POINTER(_u64p)]),
+            "orc_gen_galois_key": (None, [_vp, _u64p, _u32, _u64, ctypes.POINTER(_u64p)]),
             "orc_fnv1a64": (_u64, [_u64p, _sz]),
             "orc_fill_uniform": (None, [_u64p, _sz, _u64, _u64]),
         }
@@ -237,6 +249,58 @@ class Oracle:
         res = np.zeros((3, limbs, self.n), dtype=np.uint64)
         lib().orc_tensor_prod_2x2(self._h, p(np.ascontiguousarray(op1)), p(np.ascontiguousarray(op2)), limbs, p(res))
         return res
+
+    # ---- key generation / encryption / decryption (oracle.c "Key generation") ---------------
+    def level_limbs(self, chain_index):
+        return self.size_QP if chain_index == 0 else self.size_Q - (chain_index - 1)
+
+    def sample(self, kind, limbs, seed):
+        out = np.zeros((limbs, self.n), dtype=np.uint64)
+        getattr(lib(), "orc_sample_" + kind)(self._h, p(out), limbs, None, seed)
+        return out
+
+    def gen_secretkey(self, seed):
+        sk = np.zeros((self.size_QP, self.n), dtype=np.uint64)
+        lib().orc_gen_secretkey(self._h, seed, p(sk))
+        return sk
+
+    def encrypt_zero_symmetric(self, sk, chain_index, seed_a, seed_e):
+        ct = np.zeros((2, self.level_limbs(chain_index), self.n), dtype=np.uint64)
+        lib().orc_encrypt_zero_symmetric(self._h, p(sk), chain_index, seed_a, seed_e, p(ct))
+        return ct
+
+    def encrypt_symmetric(self, sk, plain, chain_index, seed_a, seed_e):
+        ct = np.zeros((2, self.level_limbs(chain_index), self.n), dtype=np.uint64)
+        lib().orc_encrypt_symmetric(self._h, p(sk), p(np.ascontiguousarray(plain)), chain_index, seed_a, seed_e, p(ct))
+        return ct
+
+    def ckks_decrypt(self, sk, ct, chain_index):
+        ct = np.ascontiguousarray(ct)
+        plain = np.zeros((self.level_limbs(chain_index), self.n), dtype=np.uint64)
+        lib().orc_ckks_decrypt(self._h, p(sk), p(ct), ct.shape[0], chain_index, p(plain))
+        return plain
+
+    def _new_evk(self):
+        return [np.zeros((2, self.size_QP, self.n), dtype=np.uint64) for _ in range(self.size_Q // self.size_P)]
+
+    def generate_one_kswitch_key(self, sk, new_key, seed):
+        evk = self._new_evk()
+        lib().orc_generate_one_kswitch_key(self._h, p(sk), p(np.ascontiguousarray(new_key)), seed, self._evk_ptrs(evk))
+        return evk
+
+    def gen_relinkey(self, sk, seed):
+        evk = self._new_evk()
+        lib().orc_gen_relinkey(self._h, p(sk), seed, self._evk_ptrs(evk))
+        return evk
+
+    def gen_galois_key(self, sk, elt, seed):
+        evk = self._new_evk()
+        lib().orc_gen_galois_key(self._h, p(sk), elt, seed, self._evk_ptrs(evk))
+        return evk
+
+
+def rnd_at(seed, ctr):
+    return int(lib().orc_rnd_at(seed, ctr))
 
 
 def galois_table(log_n, elt):

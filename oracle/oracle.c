@@ -706,3 +706,154 @@ void orc_fill_uniform(uint64_t *out, size_t count, uint64_t q, uint64_t seed) {
         out[i] = v;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Key generation, symmetric encryption, decryption.
+ *
+ * Structure follows src/secretkey.cu (gen_secretkey :368-440, encrypt_zero_symmetric :207-263,
+ * generate_one_kswitch_key :265-310 + src/polymath.cu:323-343, gen_relinkey :452-477,
+ * create_galois_keys :479-521, ckks_decrypt :584-624) and the samplers of src/prng.cu
+ * (ternary :142-163, centred binomial :219-242, uniform by rejection :174-207).
+ * Randomness is this project's own SEEDED, counter-based generator (the reference draws seeds
+ * from std::random_device and expands them with a stream cipher, so its outputs are not
+ * reproducible by design, and this fork's "uniform" sampler stores the constant 1,
+ * src/prng.cu:201-203 — the sampler here is the uniform one the comment there describes):
+ *     rnd(seed, ctr) = SplitMix64 output number ctr+1 of the stream started at `seed`
+ * which is random-access, so the GPU computes every coefficient independently.
+ * ---------------------------------------------------------------------------------------- */
+static inline uint64_t rnd_at(uint64_t seed, uint64_t ctr) {
+    uint64_t s = seed + ctr * 0x9E3779B97F4A7C15ULL;
+    return splitmix64(&s);
+}
+
+uint64_t orc_rnd_at(uint64_t seed, uint64_t ctr) { return rnd_at(seed, ctr); }
+
+/* src/prng.cu:142-163: first byte mod 3, minus 1; the same coefficient in every limb */
+void orc_sample_ternary(const orc_ctx *c, uint64_t *out, size_t limbs, const size_t *table_idx, uint64_t seed) {
+    for (size_t l = 0; l < limbs; l++) {
+        const uint64_t q = c->q[table_idx ? table_idx[l] : l];
+        for (size_t k = 0; k < c->n; k++) {
+            const uint64_t t = (rnd_at(seed, k) & 0xFF) % 3;
+            out[l * c->n + k] = t == 0 ? q - 1 : t - 1;
+        }
+    }
+}
+
+/* src/prng.cu:219-242: centred binomial over 21 + 21 bits of the first six bytes */
+void orc_sample_error(const orc_ctx *c, uint64_t *out, size_t limbs, const size_t *table_idx, uint64_t seed) {
+    for (size_t l = 0; l < limbs; l++) {
+        const uint64_t q = c->q[table_idx ? table_idx[l] : l];
+        for (size_t k = 0; k < c->n; k++) {
+            const uint64_t r = rnd_at(seed, k);
+            const int cbd = __builtin_popcountll(r & 0x1FFFFFULL) - __builtin_popcountll((r >> 24) & 0x1FFFFFULL);
+            out[l * c->n + k] = cbd < 0 ? q - (uint64_t)(-cbd) : (uint64_t)cbd;
+        }
+    }
+}
+
+/* src/prng.cu:174-207: reject above the largest multiple of q, then reduce; attempt a of element
+ * (l, k) uses counter l*n + k + a*limbs*n */
+void orc_sample_uniform(const orc_ctx *c, uint64_t *out, size_t limbs, const size_t *table_idx, uint64_t seed) {
+    const uint64_t total = (uint64_t)limbs * c->n;
+    for (size_t l = 0; l < limbs; l++) {
+        const uint64_t q = c->q[table_idx ? table_idx[l] : l];
+        const uint64_t max_multiple = ~0ULL - (~0ULL % q) - 1;
+        for (size_t k = 0; k < c->n; k++) {
+            uint64_t ctr = l * c->n + k, r;
+            while ((r = rnd_at(seed, ctr)) > max_multiple) ctr += total;
+            out[l * c->n + k] = r % q;
+        }
+    }
+}
+
+/* limbs of a level: chain_index 0 = key level (all of Q u P), i >= 1 = the first size_Q-(i-1)
+ * limbs of Q (include/context.cuh get_context_data) */
+static size_t level_limbs(const orc_ctx *c, size_t chain_index) {
+    return chain_index == 0 ? c->size_QP : c->size_QP - c->size_P - (chain_index - 1);
+}
+
+/* src/secretkey.cu:368-440: ternary coefficients, NTT form over all key-level limbs */
+void orc_gen_secretkey(const orc_ctx *c, uint64_t seed, uint64_t *sk) {
+    orc_sample_ternary(c, sk, c->size_QP, NULL, seed);
+    for (size_t l = 0; l < c->size_QP; l++) orc_ntt_fwd(c, sk + l * c->n, l);
+}
+
+/* src/secretkey.cu:207-263 (is_ntt_form = true): (c0, c1) = (-(a*s + e), a) */
+void orc_encrypt_zero_symmetric(const orc_ctx *c, const uint64_t *sk, size_t chain_index, uint64_t seed_a,
+                                uint64_t seed_e, uint64_t *ct) {
+    const size_t limbs = level_limbs(c, chain_index), n = c->n;
+    uint64_t *c0 = ct, *c1 = ct + limbs * n;
+    orc_sample_error(c, c0, limbs, NULL, seed_e);
+    for (size_t l = 0; l < limbs; l++) orc_ntt_fwd(c, c0 + l * n, l);
+    orc_sample_uniform(c, c1, limbs, NULL, seed_a);
+    for (size_t l = 0; l < limbs; l++) {
+        const uint64_t q = c->q[l];
+        for (size_t k = 0; k < n; k++) {
+            const uint64_t v = addmod(mulmod(c1[l * n + k], sk[l * n + k], q), c0[l * n + k], q);
+            c0[l * n + k] = v ? q - v : 0;
+        }
+    }
+}
+
+/* src/secretkey.cu:548-582: c0 += plain (plain in NTT form at the same level) */
+void orc_encrypt_symmetric(const orc_ctx *c, const uint64_t *sk, const uint64_t *plain, size_t chain_index,
+                           uint64_t seed_a, uint64_t seed_e, uint64_t *ct) {
+    const size_t limbs = level_limbs(c, chain_index), n = c->n;
+    orc_encrypt_zero_symmetric(c, sk, chain_index, seed_a, seed_e, ct);
+    for (size_t l = 0; l < limbs; l++)
+        for (size_t k = 0; k < n; k++) ct[l * n + k] = addmod(ct[l * n + k], plain[l * n + k], c->q[l]);
+}
+
+/* src/secretkey.cu:584-624: plain = c0 + sum_i c_i * s^i (NTT form) */
+void orc_ckks_decrypt(const orc_ctx *c, const uint64_t *sk, const uint64_t *ct, size_t cipher_size, size_t chain_index,
+                      uint64_t *plain) {
+    const size_t limbs = level_limbs(c, chain_index), n = c->n;
+    for (size_t l = 0; l < limbs; l++) {
+        const uint64_t q = c->q[l];
+        for (size_t k = 0; k < n; k++) {
+            uint64_t acc = ct[l * n + k], sp = 1;
+            for (size_t i = 1; i < cipher_size; i++) {
+                sp = mulmod(sp, sk[l * n + k], q);
+                acc = addmod(acc, mulmod(ct[(i * limbs + l) * n + k], sp, q), q);
+            }
+            plain[l * n + k] = acc;
+        }
+    }
+}
+
+/* src/secretkey.cu:265-310 + src/polymath.cu:323-343: dnum = size_Q/size_P encryptions of zero at
+ * key level; digit d's b-part gets (P mod q_j) * new_key_j on limbs j in [d*alpha, (d+1)*alpha).
+ * Digit d draws (seed_a, seed_e) = (rnd(seed, 2d), rnd(seed, 2d+1)).  evks[d]: [2][size_QP][n]. */
+void orc_generate_one_kswitch_key(const orc_ctx *c, const uint64_t *sk, const uint64_t *new_key, uint64_t seed,
+                                  uint64_t *const *evks) {
+    const size_t n = c->n, alpha = c->size_P, size_Q = c->size_QP - c->size_P, dnum = size_Q / alpha;
+    for (size_t d = 0; d < dnum; d++) {
+        orc_encrypt_zero_symmetric(c, sk, 0, rnd_at(seed, 2 * d), rnd_at(seed, 2 * d + 1), evks[d]);
+        for (size_t j = d * alpha; j < (d + 1) * alpha; j++) {
+            const uint64_t q = c->q[j];
+            uint64_t bigP = 1;
+            for (size_t k = 0; k < alpha; k++) bigP = mulmod(bigP, c->q[size_Q + k] % q, q);
+            for (size_t k = 0; k < n; k++)
+                evks[d][j * n + k] = addmod(evks[d][j * n + k], mulmod(new_key[j * n + k], bigP, q), q);
+        }
+    }
+}
+
+/* src/secretkey.cu:452-477: s' = s^2 */
+void orc_gen_relinkey(const orc_ctx *c, const uint64_t *sk, uint64_t seed, uint64_t *const *evks) {
+    const size_t n = c->n, size_Q = c->size_QP - c->size_P;
+    uint64_t *s2 = (uint64_t *)malloc(size_Q * n * sizeof(uint64_t));
+    for (size_t l = 0; l < size_Q; l++)
+        for (size_t k = 0; k < n; k++) s2[l * n + k] = mulmod(sk[l * n + k], sk[l * n + k], c->q[l]);
+    orc_generate_one_kswitch_key(c, sk, s2, seed, evks);
+    free(s2);
+}
+
+/* src/secretkey.cu:479-521: s' = s(X^g), the NTT-domain permutation of the secret key */
+void orc_gen_galois_key(const orc_ctx *c, const uint64_t *sk, uint32_t galois_elt, uint64_t seed, uint64_t *const *evks) {
+    const size_t n = c->n, size_Q = c->size_QP - c->size_P;
+    uint64_t *sg = (uint64_t *)malloc(size_Q * n * sizeof(uint64_t));
+    orc_apply_galois_ntt(c->log_n, sk, size_Q, galois_elt, sg);
+    orc_generate_one_kswitch_key(c, sk, sg, seed, evks);
+    free(sg);
+}

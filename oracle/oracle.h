@@ -88,6 +88,24 @@ void orc_pointwise_mul(const orc_ctx *c, const uint64_t *a, const uint64_t *b, u
 uint64_t orc_fnv1a64(const uint64_t *data, size_t words);
 void orc_fill_uniform(uint64_t *out, size_t count, uint64_t q, uint64_t seed);
 
+/* key generation / symmetric encryption / decryption with the project's seeded generator
+ * (oracle.c, "Key generation"; src/secretkey.cu, src/prng.cu) */
+uint64_t orc_rnd_at(uint64_t seed, uint64_t ctr);
+void orc_sample_ternary(const orc_ctx *c, uint64_t *out, size_t limbs, const size_t *table_idx, uint64_t seed);
+void orc_sample_error(const orc_ctx *c, uint64_t *out, size_t limbs, const size_t *table_idx, uint64_t seed);
+void orc_sample_uniform(const orc_ctx *c, uint64_t *out, size_t limbs, const size_t *table_idx, uint64_t seed);
+void orc_gen_secretkey(const orc_ctx *c, uint64_t seed, uint64_t *sk);
+void orc_encrypt_zero_symmetric(const orc_ctx *c, const uint64_t *sk, size_t chain_index, uint64_t seed_a,
+                                uint64_t seed_e, uint64_t *ct);
+void orc_encrypt_symmetric(const orc_ctx *c, const uint64_t *sk, const uint64_t *plain, size_t chain_index,
+                           uint64_t seed_a, uint64_t seed_e, uint64_t *ct);
+void orc_ckks_decrypt(const orc_ctx *c, const uint64_t *sk, const uint64_t *ct, size_t cipher_size, size_t chain_index,
+                      uint64_t *plain);
+void orc_generate_one_kswitch_key(const orc_ctx *c, const uint64_t *sk, const uint64_t *new_key, uint64_t seed,
+                                  uint64_t *const *evks);
+void orc_gen_relinkey(const orc_ctx *c, const uint64_t *sk, uint64_t seed, uint64_t *const *evks);
+void orc_gen_galois_key(const orc_ctx *c, const uint64_t *sk, uint32_t galois_elt, uint64_t seed, uint64_t *const *evks);
+
 #ifdef __cplusplus
 }
 #endif

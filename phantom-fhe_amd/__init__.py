@@ -74,6 +74,13 @@ SIGNATURES = {
     "pha_multiply_and_relin_inplace": (_int, [_vp, _sz, _vp, _vp, _vp, _vp]),
     "pha_apply_galois_inplace": (_int, [_vp, _sz, _vp, _u32, _vp, _vp]),
     "pha_rescale_to_next": (_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "pha_gen_secretkey": (_int, [_vp, _u64, _vp, _vp]),
+    "pha_encrypt_zero_symmetric": (_int, [_vp, _vp, _sz, _u64, _u64, _vp, _vp]),
+    "pha_encrypt_symmetric": (_int, [_vp, _vp, _vp, _sz, _u64, _u64, _vp, _vp]),
+    "pha_ckks_decrypt": (_int, [_vp, _vp, _vp, _sz, _sz, _vp, _vp]),
+    "pha_generate_one_kswitch_key": (_int, [_vp, _vp, _vp, _u64, ctypes.POINTER(_vp), _vp]),
+    "pha_gen_relinkey": (_int, [_vp, _vp, _u64, ctypes.POINTER(_vp), _vp]),
+    "pha_gen_galois_key": (_int, [_vp, _vp, _u32, _u64, ctypes.POINTER(_vp), _vp]),
     "pha_lp_modup_begin": (_int, [_vp, _sz, _vp, _vp, _sz, _sz, _vp]),
     "pha_lp_modup_finish": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "pha_lp_key_switch_inner_prod": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
@@ -326,6 +333,54 @@ class PhantomContext:
 
     def rescale_to_next(self, chain_index, src, cipher_size, dst):
         _check(lib().pha_rescale_to_next(self._h, chain_index, _ptr(src), cipher_size, _ptr(dst), _stream()))
+
+    # PhantomSecretKey (include/secretkey.h:150-290) ------------------------------------------
+    def level_limbs(self, chain_index):
+        return self.size_QP if chain_index == 0 else self.size_Q - (chain_index - 1)
+
+    def _empty(self, *shape):
+        import torch
+        return torch.empty((*shape, self.n), dtype=torch.int64, device="cuda")
+
+    def gen_secretkey(self, seed):
+        sk = self._empty(self.size_QP)
+        _check(lib().pha_gen_secretkey(self._h, seed, _ptr(sk), _stream()))
+        return sk
+
+    def encrypt_zero_symmetric(self, sk, chain_index, seed_a, seed_e):
+        ct = self._empty(2, self.level_limbs(chain_index))
+        _check(lib().pha_encrypt_zero_symmetric(self._h, _ptr(sk), chain_index, seed_a, seed_e, _ptr(ct), _stream()))
+        return ct
+
+    def encrypt_symmetric(self, sk, plain, chain_index, seed_a, seed_e):
+        ct = self._empty(2, self.level_limbs(chain_index))
+        _check(lib().pha_encrypt_symmetric(self._h, _ptr(sk), _ptr(plain), chain_index, seed_a, seed_e, _ptr(ct),
+                                           _stream()))
+        return ct
+
+    def ckks_decrypt(self, sk, ct, chain_index):
+        plain = self._empty(self.level_limbs(chain_index))
+        _check(lib().pha_ckks_decrypt(self._h, _ptr(sk), _ptr(ct), ct.shape[0], chain_index, _ptr(plain), _stream()))
+        return plain
+
+    def _new_evk(self):
+        digits = [self._empty(2, self.size_QP) for _ in range(self.size_Q // self.size_P)]
+        return digits, (_vp * len(digits))(*[d.data_ptr() for d in digits])
+
+    def generate_one_kswitch_key(self, sk, new_key, seed):
+        digits, arr = self._new_evk()
+        _check(lib().pha_generate_one_kswitch_key(self._h, _ptr(sk), _ptr(new_key), seed, arr, _stream()))
+        return EvalKey(digits)
+
+    def gen_relinkey(self, sk, seed):
+        digits, arr = self._new_evk()
+        _check(lib().pha_gen_relinkey(self._h, _ptr(sk), seed, arr, _stream()))
+        return EvalKey(digits)
+
+    def gen_galois_key(self, sk, galois_elt, seed):
+        digits, arr = self._new_evk()
+        _check(lib().pha_gen_galois_key(self._h, _ptr(sk), galois_elt, seed, arr, _stream()))
+        return EvalKey(digits)
 
     # limb-parallel steps (include/phantom_amd.h "limb-parallel key switch"); w = (q_begin, q_count,
     # p_begin, p_count), orchestrated by limb_parallel.LimbParallelEvaluator ------------------

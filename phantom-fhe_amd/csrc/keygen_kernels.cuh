@@ -1,0 +1,85 @@
+// Samplers and element-wise kernels of key generation, symmetric encryption and decryption
+// (SURVEY.md §8f.1).  Distributions follow src/prng.cu of the reference (ternary :142-163,
+// centred binomial :219-242, uniform by rejection :174-207); the generator is this project's
+// seeded, random-access one — rnd(seed, ctr) = output ctr+1 of the SplitMix64 stream started at
+// `seed` — so that every coefficient is computed independently and runs are reproducible (the
+// reference seeds from std::random_device).  Element-wise arithmetic restates src/polymath.cu.
+#pragma once
+
+#include "modarith.cuh"
+
+namespace pha {
+
+__device__ __forceinline__ uint64_t rnd_at(uint64_t seed, uint64_t ctr) {
+    uint64_t z = seed + (ctr + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+enum : int { SAMPLE_TERNARY = 0, SAMPLE_ERROR = 1, SAMPLE_UNIFORM = 2 };
+
+// out[l][k] for l < limbs (limb l is modulo mod[l]); one lane per coefficient, looping over limbs
+// for the two small distributions so that the draw is shared by every limb
+template <int KIND>
+__global__ __launch_bounds__(256) void sample_poly_kernel(uint64_t *out, const DModulus *mod, uint32_t limbs, uint32_t n,
+                                                          uint64_t seed) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (KIND == SAMPLE_UNIFORM) {
+        const uint32_t l = blockIdx.y;
+        const DModulus m = mod[l];
+        const uint64_t total = static_cast<uint64_t>(limbs) * n;
+        // largest r accepted: 2^64 - 1 - ((2^64 - 1) mod q) - 1 (src/prng.cu:188)
+        const uint64_t max_multiple = ~0ull - barrett64(~0ull, m.value, m.ratio1) - 1;
+        uint64_t ctr = static_cast<uint64_t>(l) * n + k, r;
+        while ((r = rnd_at(seed, ctr)) > max_multiple) ctr += total;
+        out[static_cast<size_t>(l) * n + k] = barrett64(r, m.value, m.ratio1);
+    } else {
+        const uint64_t r = rnd_at(seed, k);
+        int v;
+        if (KIND == SAMPLE_TERNARY)
+            v = static_cast<int>((r & 0xFF) % 3) - 1;
+        else
+            v = __popcll(r & 0x1FFFFFull) - __popcll((r >> 24) & 0x1FFFFFull);
+        for (uint32_t l = 0; l < limbs; l++)
+            out[static_cast<size_t>(l) * n + k] = v < 0 ? mod[l].value - static_cast<uint64_t>(-v) : static_cast<uint64_t>(v);
+    }
+}
+
+enum : int { EW_MUL = 0, EW_MUL_ADD = 1, EW_MUL_ADD_NEG = 2, EW_ADD = 3, EW_MUL_CONST_ADD = 4 };
+
+// limb-wise element-wise arithmetic, 16 B per lane (src/polymath.cu: multiply_rns_poly,
+// multiply_and_add_rns_poly, multiply_and_add_negate_rns_poly :345-380, add_rns_poly,
+// multiply_temp_mod_and_add_rns_poly :323-343); limb l of the buffers is modulo mod[l]
+template <int OP>
+__global__ __launch_bounds__(256) void elementwise_kernel(uint64_t *dst, const uint64_t *a, const uint64_t *b,
+                                                          const uint64_t *c, const DModulus *mod, const uint64_t *cst,
+                                                          uint32_t n) {
+    const uint32_t per_limb = n / 512;
+    const uint32_t l = blockIdx.x / per_limb;
+    const size_t id = static_cast<size_t>(l) * n + ((blockIdx.x % per_limb) * 256 + threadIdx.x) * 2;
+    const DModulus m = mod[l];
+    const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(a + id);
+    ulonglong2 y = {0, 0}, z = {0, 0}, r;
+    if (OP != EW_MUL_CONST_ADD) y = *reinterpret_cast<const ulonglong2 *>(b + id);
+    if (OP == EW_MUL_ADD || OP == EW_MUL_ADD_NEG || OP == EW_MUL_CONST_ADD) z = *reinterpret_cast<const ulonglong2 *>(c + id);
+    if (OP == EW_ADD) {
+        r.x = csub(x.x + y.x, m.value);
+        r.y = csub(x.y + y.y, m.value);
+    } else {
+        if (OP == EW_MUL_CONST_ADD) y.x = y.y = cst[l];
+        r.x = mul_barrett(x.x, y.x, m);
+        r.y = mul_barrett(x.y, y.y, m);
+        if (OP != EW_MUL) {
+            r.x = csub(r.x + z.x, m.value);
+            r.y = csub(r.y + z.y, m.value);
+        }
+        if (OP == EW_MUL_ADD_NEG) {
+            r.x = r.x ? m.value - r.x : 0;
+            r.y = r.y ? m.value - r.y : 0;
+        }
+    }
+    *reinterpret_cast<ulonglong2 *>(dst + id) = r;
+}
+
+}  // namespace pha

@@ -17,6 +17,7 @@
 #include "ntt_kernels.cuh"
 #include "numth.hpp"
 #include "rns_kernels.cuh"
+#include "keygen_kernels.cuh"
 
 using namespace pha;
 
@@ -125,6 +126,7 @@ struct pha_context {
     std::map<size_t, std::unique_ptr<LevelTool>> levels;
     std::map<uint32_t, std::unique_ptr<DevBuf<uint32_t>>> galois_tables;
     DevBuf<uint64_t> workspace;
+    DevBuf<uint64_t> d_bigP_mod_q;  // key level, [size_Q] (key generation)
 
     NttTables fwd_tables() const {
         return NttTables{d_mod.p, d_tw.p, d_twD.p, d_n_inv.p, d_n_inv_shoup.p, static_cast<uint32_t>(log_n), twD_stride,
@@ -705,6 +707,81 @@ int lp_rescale_finish(pha_context *ctx, LevelTool *lt, const uint64_t *src, cons
     return ntt_forward(ctx, dst, cipher_size, next * n, r, EPI_SUB_MUL, ep, st);
 }
 
+// ---- key generation / encryption / decryption -------------------------------
+uint64_t host_rnd_at(uint64_t seed, uint64_t ctr) {  // same stream as rnd_at() in keygen_kernels.cuh
+    uint64_t z = seed + (ctr + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// chain_index 0 = key level (all of Q u P), i >= 1 = the first size_Q-(i-1) limbs of Q
+int level_limbs(const pha_context *ctx, size_t chain_index, size_t *limbs) {
+    if (chain_index > ctx->size_Q) return fail(PHA_ERR_INVALID_ARGUMENT, "chain_index %zu out of range", chain_index);
+    *limbs = chain_index == 0 ? ctx->size_QP : ctx->size_Q - (chain_index - 1);
+    return PHA_OK;
+}
+
+int launch_sample(pha_context *ctx, int kind, uint64_t *out, size_t limbs, uint64_t seed, hipStream_t st) {
+    const uint32_t n = static_cast<uint32_t>(ctx->n), L = static_cast<uint32_t>(limbs);
+    if (kind == SAMPLE_UNIFORM)
+        hipLaunchKernelGGL((sample_poly_kernel<SAMPLE_UNIFORM>), dim3(n / 256, L), dim3(256), 0, st, out, ctx->d_mod.p, L, n, seed);
+    else if (kind == SAMPLE_TERNARY)
+        hipLaunchKernelGGL((sample_poly_kernel<SAMPLE_TERNARY>), dim3(n / 256), dim3(256), 0, st, out, ctx->d_mod.p, L, n, seed);
+    else
+        hipLaunchKernelGGL((sample_poly_kernel<SAMPLE_ERROR>), dim3(n / 256), dim3(256), 0, st, out, ctx->d_mod.p, L, n, seed);
+    return check_launch("sample_poly");
+}
+
+// limbs [limb0, limb0+limbs) of the chain; buffer pointers already point at limb0
+int launch_ew(pha_context *ctx, int op, uint64_t *dst, const uint64_t *a, const uint64_t *b, const uint64_t *c,
+              const uint64_t *cst, size_t limb0, size_t limbs, hipStream_t st) {
+    const uint32_t n = static_cast<uint32_t>(ctx->n);
+    const dim3 grid(static_cast<uint32_t>(limbs) * (n / 512));
+    const DModulus *mod = ctx->d_mod.p + limb0;
+#define EW_CASE(OP) case OP: hipLaunchKernelGGL((elementwise_kernel<OP>), grid, dim3(256), 0, st, dst, a, b, c, mod, cst, n); break;
+    switch (op) {
+        EW_CASE(EW_MUL) EW_CASE(EW_MUL_ADD) EW_CASE(EW_MUL_ADD_NEG) EW_CASE(EW_ADD) EW_CASE(EW_MUL_CONST_ADD)
+    }
+#undef EW_CASE
+    return check_launch("elementwise");
+}
+
+// src/secretkey.cu:207-263 with is_ntt_form = true
+int do_encrypt_zero(pha_context *ctx, const uint64_t *sk, size_t chain_index, uint64_t seed_a, uint64_t seed_e, uint64_t *ct,
+                    hipStream_t st) {
+    size_t limbs;
+    PHA_TRY(level_limbs(ctx, chain_index, &limbs));
+    uint64_t *c0 = ct, *c1 = ct + limbs * ctx->n;
+    PHA_TRY(launch_sample(ctx, SAMPLE_ERROR, c0, limbs, seed_e, st));
+    NttRange r;
+    PHA_TRY(make_range(ctx, limbs, 0, 0, 0, 0, 0, r));
+    PHA_TRY(ntt_forward(ctx, c0, 1, 0, r, EPI_NONE, Epilogue{}, st));
+    PHA_TRY(launch_sample(ctx, SAMPLE_UNIFORM, c1, limbs, seed_a, st));
+    return launch_ew(ctx, EW_MUL_ADD_NEG, c0, c1, sk, c0, nullptr, 0, limbs, st);
+}
+
+// src/secretkey.cu:265-310, src/polymath.cu:323-343; evks: HOST array of dnum device buffers
+int do_kswitch_key(pha_context *ctx, const uint64_t *sk, const uint64_t *new_key, uint64_t seed, uint64_t *const *evks,
+                   hipStream_t st) {
+    if (ctx->size_P == 0 || ctx->size_Q % ctx->size_P)
+        return fail(PHA_ERR_LOGIC, "key switching keys need size_P > 0 dividing size_Q (dnum = size_Q / size_P)");
+    const size_t n = ctx->n, alpha = ctx->size_P, dnum = ctx->size_Q / alpha;
+    if (!ctx->d_bigP_mod_q.p) {
+        LevelConstants lc;
+        build_level_constants(ctx->moduli, ctx->size_P, ctx->size_Q, lc);
+        HIP_TRY(ctx->d_bigP_mod_q.upload(lc.bigP_mod_q));
+    }
+    for (size_t d = 0; d < dnum; d++) {
+        if (!evks[d]) return fail(PHA_ERR_INVALID_ARGUMENT, "null key buffer");
+        PHA_TRY(do_encrypt_zero(ctx, sk, 0, host_rnd_at(seed, 2 * d), host_rnd_at(seed, 2 * d + 1), evks[d], st));
+        const size_t j0 = d * alpha;
+        PHA_TRY(launch_ew(ctx, EW_MUL_CONST_ADD, evks[d] + j0 * n, new_key + j0 * n, nullptr, evks[d] + j0 * n,
+                          ctx->d_bigP_mod_q.p + j0, j0, alpha, st));
+    }
+    return PHA_OK;
+}
+
 int get_galois_table(pha_context *ctx, uint32_t elt, const uint32_t **out) {
     if (!(elt & 1) || elt >= 2 * ctx->n) return fail(PHA_ERR_INVALID_ARGUMENT, "Galois element is not valid");
     auto it = ctx->galois_tables.find(elt);
@@ -1194,6 +1271,79 @@ int pha_lp_rescale_finish(pha_context *ctx, size_t chain_index, const uint64_t *
     LP_PROLOGUE(src && last_coeff && dst);
     if (lt->size_Ql < 2) return fail(PHA_ERR_INVALID_ARGUMENT, "end of modulus switching chain reached");
     return lp_rescale_finish(ctx, lt, src, last_coeff, cipher_size, dst, w, as_stream(stream));
+}
+
+// ---- key generation, symmetric encryption, decryption -----------------------
+int pha_gen_secretkey(pha_context *ctx, uint64_t seed, uint64_t *sk, pha_stream_t stream) {
+    REQUIRE_CTX(sk);
+    hipStream_t st = as_stream(stream);
+    PHA_TRY(launch_sample(ctx, SAMPLE_TERNARY, sk, ctx->size_QP, seed, st));
+    NttRange r;
+    PHA_TRY(make_range(ctx, ctx->size_QP, 0, 0, 0, 0, 0, r));
+    return ntt_forward(ctx, sk, 1, 0, r, EPI_NONE, Epilogue{}, st);
+}
+
+int pha_encrypt_zero_symmetric(pha_context *ctx, const uint64_t *sk, size_t chain_index, uint64_t seed_a, uint64_t seed_e,
+                               uint64_t *ct, pha_stream_t stream) {
+    REQUIRE_CTX(sk && ct);
+    return do_encrypt_zero(ctx, sk, chain_index, seed_a, seed_e, ct, as_stream(stream));
+}
+
+int pha_encrypt_symmetric(pha_context *ctx, const uint64_t *sk, const uint64_t *plain, size_t chain_index, uint64_t seed_a,
+                          uint64_t seed_e, uint64_t *ct, pha_stream_t stream) {
+    REQUIRE_CTX(sk && plain && ct);
+    size_t limbs;
+    PHA_TRY(level_limbs(ctx, chain_index, &limbs));
+    PHA_TRY(do_encrypt_zero(ctx, sk, chain_index, seed_a, seed_e, ct, as_stream(stream)));
+    return launch_ew(ctx, EW_ADD, ct, ct, plain, nullptr, nullptr, 0, limbs, as_stream(stream));
+}
+
+int pha_ckks_decrypt(pha_context *ctx, const uint64_t *sk, const uint64_t *ct, size_t cipher_size, size_t chain_index,
+                     uint64_t *plain, pha_stream_t stream) {
+    REQUIRE_CTX(sk && ct && plain);
+    if (cipher_size < 2) return fail(PHA_ERR_INVALID_ARGUMENT, "encrypted is not valid for encryption parameters");
+    size_t limbs;
+    PHA_TRY(level_limbs(ctx, chain_index, &limbs));
+    hipStream_t st = as_stream(stream);
+    const size_t n = ctx->n;
+    // plain = c0 + c1*s (+ c2*s^2 ...): powers of s kept in the workspace
+    PHA_TRY(launch_ew(ctx, EW_MUL_ADD, plain, ct + limbs * n, sk, ct, nullptr, 0, limbs, st));
+    if (cipher_size > 2) {
+        uint64_t *sp;
+        PHA_TRY(ensure_workspace(ctx, limbs * n, &sp));
+        const uint64_t *prev = sk;
+        for (size_t i = 2; i < cipher_size; i++) {
+            PHA_TRY(launch_ew(ctx, EW_MUL, sp, prev, sk, nullptr, nullptr, 0, limbs, st));
+            PHA_TRY(launch_ew(ctx, EW_MUL_ADD, plain, ct + i * limbs * n, sp, plain, nullptr, 0, limbs, st));
+            prev = sp;
+        }
+    }
+    return PHA_OK;
+}
+
+int pha_generate_one_kswitch_key(pha_context *ctx, const uint64_t *sk, const uint64_t *new_key, uint64_t seed,
+                                 uint64_t *const *evks_host, pha_stream_t stream) {
+    REQUIRE_CTX(sk && new_key && evks_host);
+    return do_kswitch_key(ctx, sk, new_key, seed, evks_host, as_stream(stream));
+}
+
+int pha_gen_relinkey(pha_context *ctx, const uint64_t *sk, uint64_t seed, uint64_t *const *evks_host, pha_stream_t stream) {
+    REQUIRE_CTX(sk && evks_host);
+    uint64_t *s2;
+    PHA_TRY(ensure_workspace(ctx, ctx->size_Q * ctx->n, &s2));
+    PHA_TRY(launch_ew(ctx, EW_MUL, s2, sk, sk, nullptr, nullptr, 0, ctx->size_Q, as_stream(stream)));
+    return do_kswitch_key(ctx, sk, s2, seed, evks_host, as_stream(stream));
+}
+
+int pha_gen_galois_key(pha_context *ctx, const uint64_t *sk, uint32_t galois_elt, uint64_t seed, uint64_t *const *evks_host,
+                       pha_stream_t stream) {
+    REQUIRE_CTX(sk && evks_host);
+    const uint32_t *perm;
+    PHA_TRY(get_galois_table(ctx, galois_elt, &perm));
+    uint64_t *sg;
+    PHA_TRY(ensure_workspace(ctx, ctx->size_Q * ctx->n, &sg));
+    PHA_TRY(do_galois(ctx, sk, ctx->size_Q, perm, sg, as_stream(stream)));
+    return do_kswitch_key(ctx, sk, sg, seed, evks_host, as_stream(stream));
 }
 
 }  // extern "C"

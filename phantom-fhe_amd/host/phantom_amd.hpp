@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <map>
 #include <memory>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -218,6 +219,119 @@ public:
         auto it = keys_.find(galois_elt);
         if (it == keys_.end()) throw std::invalid_argument("Galois elt not present");
         return it->second;
+    }
+};
+
+// ---- plaintext container (include/plaintext.h): RNS polynomial [l][N] in NTT form at a level ----
+class PhantomPlaintext {
+    size_t chain_index_ = 1, coeff_modulus_size_ = 0, poly_modulus_degree_ = 0;
+    double scale_ = 1.0;
+    device_words data_;
+
+public:
+    PhantomPlaintext() = default;
+    PhantomPlaintext(PhantomPlaintext &&) = default;
+    PhantomPlaintext &operator=(PhantomPlaintext &&) = default;
+    void resize(size_t coeff_modulus_size, size_t poly_modulus_degree, const hipStream_t &) {
+        if (coeff_modulus_size * poly_modulus_degree != data_.size()) data_ = device_words(coeff_modulus_size * poly_modulus_degree);
+        coeff_modulus_size_ = coeff_modulus_size, poly_modulus_degree_ = poly_modulus_degree;
+    }
+    uint64_t *data() const { return data_.get(); }
+    size_t chain_index() const { return chain_index_; }
+    size_t coeff_modulus_size() const { return coeff_modulus_size_; }
+    size_t poly_modulus_degree() const { return poly_modulus_degree_; }
+    double scale() const { return scale_; }
+    void set_chain_index(size_t c) { chain_index_ = c; }
+    void set_scale(double s) { scale_ = s; }
+};
+
+// ---- secret key (include/secretkey.h:150-290, src/secretkey.cu) -----------------------------------
+// Randomness: the reference seeds every draw from std::random_device; here one 64-bit seed given
+// at construction (default: std::random_device) determines every later draw, so runs can be
+// reproduced.  Distributions are the reference's (src/prng.cu).
+class PhantomSecretKey {
+    device_words sk_;  // secret_key_array(): [size_QP][N], NTT form
+    bool gen_flag_ = false;
+    uint64_t seed_, draws_ = 0;
+
+    uint64_t next_seed() {  // SplitMix64 over the construction seed
+        uint64_t z = seed_ + (++draws_) * 0x9E3779B97F4A7C15ULL;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        return z ^ (z >> 31);
+    }
+    PhantomRelinKey make_key(const PhantomContext &context, int kind, uint32_t galois_elt, const hipStream_t &s) {
+        const size_t size_QP = context.key_parms().coeff_modulus().size(), n = context.poly_degree();
+        if (context.size_P() == 0 || context.size_Q() % context.size_P()) throw std::invalid_argument("dnum is not an integer");
+        std::vector<device_words> digits;
+        std::vector<uint64_t *> ptrs;
+        for (size_t d = 0; d < context.size_Q() / context.size_P(); d++) {
+            digits.emplace_back(2 * size_QP * n);
+            ptrs.push_back(digits.back().get());
+        }
+        if (kind == 0)
+            check(pha_gen_relinkey(context.handle(), sk_.get(), next_seed(), ptrs.data(), s));
+        else
+            check(pha_gen_galois_key(context.handle(), sk_.get(), galois_elt, next_seed(), ptrs.data(), s));
+        return PhantomRelinKey(std::move(digits));
+    }
+
+public:
+    explicit PhantomSecretKey(const PhantomContext &context, uint64_t seed = (uint64_t(std::random_device{}()) << 32) ^ std::random_device{}())
+        : seed_(seed) {
+        gen_secretkey(context, nullptr);
+    }
+    PhantomSecretKey(PhantomSecretKey &&) = default;
+    uint64_t *secret_key_array() const { return sk_.get(); }
+
+    void gen_secretkey(const PhantomContext &context, const hipStream_t &stream) {
+        if (gen_flag_) throw std::logic_error("cannot generate secret key twice");
+        sk_ = device_words(context.key_parms().coeff_modulus().size() * context.poly_degree());
+        check(pha_gen_secretkey(context.handle(), next_seed(), sk_.get(), stream));
+        gen_flag_ = true;
+    }
+    PhantomRelinKey gen_relinkey(const PhantomContext &context, const hip_stream_wrapper &sw) {
+        return make_key(context, 0, 0, sw.get_stream());
+    }
+    PhantomGaloisKey create_galois_keys_from_elts(const PhantomContext &context, const std::vector<uint32_t> &elts,
+                                                  const hip_stream_wrapper &sw) {
+        PhantomGaloisKey gk;
+        for (uint32_t e : elts) {
+            if (!(e & 1) || e >= 2 * context.poly_degree()) throw std::invalid_argument("Galois element is not valid");
+            gk.insert(e, make_key(context, 1, e, sw.get_stream()));
+        }
+        return gk;
+    }
+    PhantomGaloisKey create_galois_keys_from_steps(const PhantomContext &context, const std::vector<int> &steps,
+                                                   const hip_stream_wrapper &sw) {
+        std::vector<uint32_t> elts;
+        for (int st : steps) {
+            uint32_t e;
+            check(pha_galois_elt_from_step(context.log_n(), st, &e));
+            elts.push_back(e);
+        }
+        return create_galois_keys_from_elts(context, elts, sw);
+    }
+    // src/secretkey.cu:548-582
+    void encrypt_symmetric(const PhantomContext &context, const PhantomPlaintext &plain, PhantomCiphertext &cipher,
+                           const hip_stream_wrapper &sw) {
+        const hipStream_t &s = sw.get_stream();
+        cipher.resize(context, plain.chain_index(), 2, s);
+        const uint64_t seed_a = next_seed(), seed_e = next_seed();
+        check(pha_encrypt_symmetric(context.handle(), sk_.get(), plain.data(), plain.chain_index(), seed_a, seed_e,
+                                    cipher.data(), s));
+        cipher.set_ntt_form(true);
+        cipher.set_scale(plain.scale());
+    }
+    // src/secretkey.cu:584-643
+    void decrypt(const PhantomContext &context, const PhantomCiphertext &cipher, PhantomPlaintext &plain,
+                 const hip_stream_wrapper &sw) {
+        if (!cipher.is_ntt_form()) throw std::invalid_argument("encrypted must be in NTT form");
+        const hipStream_t &s = sw.get_stream();
+        plain.resize(cipher.coeff_modulus_size(), cipher.poly_modulus_degree(), s);
+        check(pha_ckks_decrypt(context.handle(), sk_.get(), cipher.data(), cipher.size(), cipher.chain_index(), plain.data(), s));
+        plain.set_chain_index(cipher.chain_index());
+        plain.set_scale(cipher.scale());
     }
 };
 

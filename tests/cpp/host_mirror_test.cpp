@@ -3,6 +3,8 @@
 // parameters, context and keys, run an evaluator entry point, report the result.  Inputs are the
 // seeded uniform residues of the oracle (SplitMix64 + rejection), the results are printed as
 // FNV-1a digests and compared with the oracle by tests/test_cpp_host.py.
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
@@ -111,6 +113,42 @@ int main() {
         PhantomCiphertext rot3 = make_ct(context, moduli, 1, 47, 48, s);
         rotate_inplace(context, rot3, 3, gk, sw);
         printf("{\"rotate3_naf\": \"%016llx\"}\n", (unsigned long long)fnv(download(rot3)));
+
+        // real keys: keygen -> encrypt -> HMult+relin -> decrypt (tests/relin.cu), all on the GPU.
+        // Plaintexts are the constant polynomials 3*2^20 and 5*2^20 (in NTT form a constant is the
+        // same residue in every slot), so the product must decrypt to 15*2^40 + small noise in
+        // coefficient 0 and to noise elsewhere.
+        {
+            PhantomSecretKey sk(context, 12345);
+            PhantomRelinKey rk = sk.gen_relinkey(context, sw);
+            auto constant_plain = [&](uint64_t v) {
+                PhantomPlaintext p;
+                p.resize(context.coeff_mod_size(1), n, s);
+                std::vector<uint64_t> h(context.coeff_mod_size(1) * n, v);
+                check_hip(hipMemcpy(p.data(), h.data(), h.size() * 8, hipMemcpyHostToDevice), "upload");
+                p.set_chain_index(1);
+                p.set_scale(1048576.0);
+                return p;
+            };
+            PhantomPlaintext pa = constant_plain(3ULL << 20), pb = constant_plain(5ULL << 20), out;
+            PhantomCiphertext ca, cb;
+            sk.encrypt_symmetric(context, pa, ca, sw);
+            sk.encrypt_symmetric(context, pb, cb, sw);
+            multiply_and_relin_inplace(context, ca, cb, rk, sw);
+            sk.decrypt(context, ca, out, sw);
+            nwt_2d_radix8_backward_inplace(out.data(), context, 1, 0, s);   // limb 0 to coefficient form
+            std::vector<uint64_t> h(n);
+            check_hip(hipStreamSynchronize(s), "sync");
+            check_hip(hipMemcpy(h.data(), out.data(), n * 8, hipMemcpyDeviceToHost), "download");
+            const uint64_t q0 = moduli[0];
+            auto centred = [&](uint64_t v) { return v > q0 / 2 ? -(double)(q0 - v) : (double)v; };
+            double err0 = std::fabs(centred(h[0]) - 15.0 * 1099511627776.0), rest = 0;
+            for (size_t i = 1; i < n; i++) rest = std::max(rest, std::fabs(centred(h[i])));
+            printf("{\"real_keys_rel_err\": %.3e, \"real_keys_rest\": %.3e}\n", err0 / 1099511627776.0, rest / 1099511627776.0);
+            int twice = 0;
+            try { sk.gen_secretkey(context, s); } catch (const std::logic_error &) { twice = 1; }
+            printf("{\"gen_twice_throws\": %d}\n", twice);
+        }
 
         // error behaviour of the reference
         int caught = 0;

@@ -14,7 +14,8 @@ BIN = os.path.join(os.path.dirname(__file__), "cpp", "host_mirror_test")
 def test_header_only_layer_is_self_contained():
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "phantom-fhe_amd", "host", "phantom_amd.hpp")).read()
     for name in ("multiply_inplace", "relinearize_inplace", "rescale_to_next", "rotate_inplace", "apply_galois_inplace",
-                 "class PhantomContext", "class PhantomCiphertext", "class PhantomRelinKey", "class PhantomGaloisKey"):
+                 "class PhantomContext", "class PhantomCiphertext", "class PhantomRelinKey", "class PhantomGaloisKey",
+                 "class PhantomSecretKey", "class PhantomPlaintext", "encrypt_symmetric", "gen_relinkey"):
         assert name in hdr
     assert "oracle" not in hdr
 
@@ -71,3 +72,6 @@ def test_cpp_host_layer_against_oracle(gpu, orc):
     # step 3 = NAF (-1, +4): applied in that order (least significant digit first)
     assert res["rotate3_naf"] == digest(rotate(rotate(ct(4, 47, 48), em1), e4))
     assert res["errors_caught"] == 5
+    # keygen -> encrypt -> HMult+relin -> decrypt with real keys: product of the constants, small noise
+    assert res["real_keys_rel_err"] < 1e-3 and res["real_keys_rest"] < 1e-3
+    assert res["gen_twice_throws"] == 1
