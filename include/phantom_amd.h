@@ -237,6 +237,24 @@ int pha_gen_relinkey(pha_context *ctx, const uint64_t *sk, uint64_t seed, uint64
 int pha_gen_galois_key(pha_context *ctx, const uint64_t *sk, uint32_t galois_elt, uint64_t seed,
                        uint64_t *const *evks_host, pha_stream_t stream);
 
+/* ---- element-wise evaluator arithmetic ------------------------------------
+ * add_rns_poly / sub_rns_poly / multiply_rns_poly / negate_rns_poly of src/polymath.cu as
+ * add_inplace, sub_inplace, negate_inplace, add_plain, sub_plain and multiply_plain use them
+ * (src/evaluate.cu:20-105,442-560): a, dst are [polys][coeff_mod_size][N]; b has b_polys == polys
+ * polys, or b_polys == 1 (a plaintext applied to every poly of a).  dst may alias a. */
+int pha_add_rns_poly(pha_context *ctx, uint64_t *dst, const uint64_t *a, const uint64_t *b, size_t coeff_mod_size,
+                     size_t polys, size_t b_polys, pha_stream_t stream);
+int pha_sub_rns_poly(pha_context *ctx, uint64_t *dst, const uint64_t *a, const uint64_t *b, size_t coeff_mod_size,
+                     size_t polys, size_t b_polys, pha_stream_t stream);
+int pha_multiply_rns_poly(pha_context *ctx, uint64_t *dst, const uint64_t *a, const uint64_t *b, size_t coeff_mod_size,
+                          size_t polys, size_t b_polys, pha_stream_t stream);
+int pha_negate_rns_poly(pha_context *ctx, uint64_t *dst, const uint64_t *a, size_t coeff_mod_size, size_t polys,
+                        pha_stream_t stream);
+/* mod_switch_drop_to_next (src/evaluate.cu:618-700): dst[cipher_size][l-1][N] = src without its
+ * last limb (CKKS mod_switch_to_next; no scaling) */
+int pha_mod_switch_drop_to_next(pha_context *ctx, size_t chain_index, const uint64_t *src, size_t cipher_size,
+                                uint64_t *dst, pha_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

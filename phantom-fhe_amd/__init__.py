@@ -81,6 +81,11 @@ SIGNATURES = {
     "pha_generate_one_kswitch_key": (_int, [_vp, _vp, _vp, _u64, ctypes.POINTER(_vp), _vp]),
     "pha_gen_relinkey": (_int, [_vp, _vp, _u64, ctypes.POINTER(_vp), _vp]),
     "pha_gen_galois_key": (_int, [_vp, _vp, _u32, _u64, ctypes.POINTER(_vp), _vp]),
+    "pha_add_rns_poly": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _vp]),
+    "pha_sub_rns_poly": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _vp]),
+    "pha_multiply_rns_poly": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _vp]),
+    "pha_negate_rns_poly": (_int, [_vp, _vp, _vp, _sz, _sz, _vp]),
+    "pha_mod_switch_drop_to_next": (_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "pha_lp_modup_begin": (_int, [_vp, _sz, _vp, _vp, _sz, _sz, _vp]),
     "pha_lp_modup_finish": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "pha_lp_key_switch_inner_prod": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
@@ -333,6 +338,32 @@ class PhantomContext:
 
     def rescale_to_next(self, chain_index, src, cipher_size, dst):
         _check(lib().pha_rescale_to_next(self._h, chain_index, _ptr(src), cipher_size, _ptr(dst), _stream()))
+
+    # element-wise evaluator ops (src/evaluate.cu add/sub/negate/add_plain/sub_plain/multiply_plain) --
+    def add_inplace(self, ct1, ct2):
+        _check(lib().pha_add_rns_poly(self._h, _ptr(ct1), _ptr(ct1), _ptr(ct2), ct1.shape[-2], ct1.shape[0], ct2.shape[0]
+                                      if ct2.dim() == 3 else 1, _stream()))
+
+    def sub_inplace(self, ct1, ct2):
+        _check(lib().pha_sub_rns_poly(self._h, _ptr(ct1), _ptr(ct1), _ptr(ct2), ct1.shape[-2], ct1.shape[0], ct2.shape[0]
+                                      if ct2.dim() == 3 else 1, _stream()))
+
+    def negate_inplace(self, ct):
+        _check(lib().pha_negate_rns_poly(self._h, _ptr(ct), _ptr(ct), ct.shape[-2], ct.shape[0], _stream()))
+
+    def add_plain_inplace(self, ct, plain):
+        _check(lib().pha_add_rns_poly(self._h, _ptr(ct), _ptr(ct), _ptr(plain), ct.shape[-2], 1, 1, _stream()))
+
+    def sub_plain_inplace(self, ct, plain):
+        _check(lib().pha_sub_rns_poly(self._h, _ptr(ct), _ptr(ct), _ptr(plain), ct.shape[-2], 1, 1, _stream()))
+
+    def multiply_plain_inplace(self, ct, plain):
+        _check(lib().pha_multiply_rns_poly(self._h, _ptr(ct), _ptr(ct), _ptr(plain), ct.shape[-2], ct.shape[0], 1, _stream()))
+
+    def mod_switch_to_next(self, chain_index, ct):
+        out = self._empty(ct.shape[0], ct.shape[1] - 1)
+        _check(lib().pha_mod_switch_drop_to_next(self._h, chain_index, _ptr(ct), ct.shape[0], _ptr(out), _stream()))
+        return out
 
     # PhantomSecretKey (include/secretkey.h:150-290) ------------------------------------------
     def level_limbs(self, chain_index):

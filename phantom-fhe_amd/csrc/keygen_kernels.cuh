@@ -82,4 +82,38 @@ __global__ __launch_bounds__(256) void elementwise_kernel(uint64_t *dst, const u
     *reinterpret_cast<ulonglong2 *>(dst + id) = r;
 }
 
+enum : int { PB_ADD = 0, PB_SUB = 1, PB_MUL = 2, PB_NEG = 3 };
+
+// Ciphertext / plaintext element-wise evaluator arithmetic (src/polymath.cu add_rns_poly,
+// sub_rns_poly, multiply_rns_poly, negate_rns_poly as used by src/evaluate.cu:20-105,442-560):
+// a, dst are [polys][limbs][n]; b is the same shape, or one [limbs][n] poly applied to every poly
+// of a when b_broadcast (plaintext operand).  16 B per lane.
+template <int OP>
+__global__ __launch_bounds__(256) void poly_binary_kernel(uint64_t *dst, const uint64_t *a, const uint64_t *b,
+                                                          const DModulus *mod, uint32_t limbs, uint32_t n,
+                                                          uint32_t b_broadcast) {
+    const uint32_t per_limb = n / 512;
+    const uint32_t row = blockIdx.x / per_limb, l = row % limbs;
+    const uint32_t k = ((blockIdx.x % per_limb) * 256 + threadIdx.x) * 2;
+    const size_t id = static_cast<size_t>(row) * n + k;
+    const DModulus m = mod[l];
+    const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(a + id);
+    ulonglong2 y = {0, 0}, r;
+    if (OP != PB_NEG) y = *reinterpret_cast<const ulonglong2 *>(b + (b_broadcast ? static_cast<size_t>(l) * n + k : id));
+    if (OP == PB_ADD) {
+        r.x = csub(x.x + y.x, m.value);
+        r.y = csub(x.y + y.y, m.value);
+    } else if (OP == PB_SUB) {
+        r.x = csub(x.x + m.value - y.x, m.value);
+        r.y = csub(x.y + m.value - y.y, m.value);
+    } else if (OP == PB_MUL) {
+        r.x = mul_barrett(x.x, y.x, m);
+        r.y = mul_barrett(x.y, y.y, m);
+    } else {
+        r.x = x.x ? m.value - x.x : 0;
+        r.y = x.y ? m.value - x.y : 0;
+    }
+    *reinterpret_cast<ulonglong2 *>(dst + id) = r;
+}
+
 }  // namespace pha

@@ -421,6 +421,76 @@ inline void apply_galois_inplace(const PhantomContext &context, PhantomCiphertex
                                    key.public_keys_ptr(), stream_wrapper.get_stream()));
 }
 
+// complex conjugation = the automorphism X -> X^(2N-1) (include/evaluate.cuh:283-294, src/evaluate.cu:855-870)
+inline void complex_conjugate_inplace(const PhantomContext &context, PhantomCiphertext &encrypted,
+                                      const PhantomGaloisKey &galois_key, const hip_stream_wrapper &stream_wrapper) {
+    apply_galois_inplace(context, encrypted, static_cast<uint32_t>(2 * context.poly_degree() - 1), galois_key, stream_wrapper);
+}
+
+// ---- element-wise evaluator entry points (include/evaluate.cuh:33-112,166-256, src/evaluate.cu:20-105,442-560,618-745)
+inline void negate_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, const hip_stream_wrapper &stream_wrapper) {
+    check(pha_negate_rns_poly(context.handle(), encrypted.data(), encrypted.data(), encrypted.coeff_modulus_size(),
+                              encrypted.size(), stream_wrapper.get_stream()));
+}
+inline void add_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2,
+                        const hip_stream_wrapper &stream_wrapper) {
+    if (encrypted1.chain_index() != encrypted2.chain_index()) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+    if (encrypted1.is_ntt_form() != encrypted2.is_ntt_form()) throw std::invalid_argument("NTT form mismatch");
+    if (encrypted1.size() != encrypted2.size()) throw std::invalid_argument("poly number mismatch");
+    check(pha_add_rns_poly(context.handle(), encrypted1.data(), encrypted1.data(), encrypted2.data(),
+                           encrypted1.coeff_modulus_size(), encrypted1.size(), encrypted2.size(), stream_wrapper.get_stream()));
+}
+inline void sub_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2,
+                        const hip_stream_wrapper &stream_wrapper) {
+    if (encrypted1.chain_index() != encrypted2.chain_index()) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+    if (encrypted1.is_ntt_form() != encrypted2.is_ntt_form()) throw std::invalid_argument("NTT form mismatch");
+    if (encrypted1.size() != encrypted2.size()) throw std::invalid_argument("poly number mismatch");
+    check(pha_sub_rns_poly(context.handle(), encrypted1.data(), encrypted1.data(), encrypted2.data(),
+                           encrypted1.coeff_modulus_size(), encrypted1.size(), encrypted2.size(), stream_wrapper.get_stream()));
+}
+inline void add_plain_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, const PhantomPlaintext &plain,
+                              const hip_stream_wrapper &stream_wrapper) {
+    if (encrypted.chain_index() != plain.chain_index()) throw std::invalid_argument("encrypted and plain parameter mismatch");
+    check(pha_add_rns_poly(context.handle(), encrypted.data(), encrypted.data(), plain.data(), encrypted.coeff_modulus_size(), 1,
+                           1, stream_wrapper.get_stream()));
+}
+inline void sub_plain_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, const PhantomPlaintext &plain,
+                              const hip_stream_wrapper &stream_wrapper) {
+    if (encrypted.chain_index() != plain.chain_index()) throw std::invalid_argument("encrypted and plain parameter mismatch");
+    check(pha_sub_rns_poly(context.handle(), encrypted.data(), encrypted.data(), plain.data(), encrypted.coeff_modulus_size(), 1,
+                           1, stream_wrapper.get_stream()));
+}
+inline void multiply_plain_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, const PhantomPlaintext &plain,
+                                   const hip_stream_wrapper &stream_wrapper) {
+    if (encrypted.chain_index() != plain.chain_index()) throw std::invalid_argument("encrypted and plain parameter mismatch");
+    check(pha_multiply_rns_poly(context.handle(), encrypted.data(), encrypted.data(), plain.data(),
+                                encrypted.coeff_modulus_size(), encrypted.size(), 1, stream_wrapper.get_stream()));
+    encrypted.set_scale(encrypted.scale() * plain.scale());
+}
+// CKKS mod_switch_to_next: drop the last prime, no scaling (src/evaluate.cu:618-723)
+inline PhantomCiphertext mod_switch_to_next(const PhantomContext &context, const PhantomCiphertext &encrypted,
+                                            const hip_stream_wrapper &stream_wrapper) {
+    if (encrypted.chain_index() == context.size_Q()) throw std::invalid_argument("end of modulus switching chain reached");
+    const hipStream_t &s = stream_wrapper.get_stream();
+    PhantomCiphertext destination;
+    destination.resize(context, context.get_next_index(encrypted.chain_index()), encrypted.size(), s);
+    check(pha_mod_switch_drop_to_next(context.handle(), encrypted.chain_index(), encrypted.data(), encrypted.size(),
+                                      destination.data(), s));
+    destination.set_scale(encrypted.scale());
+    destination.set_ntt_form(encrypted.is_ntt_form());
+    return destination;
+}
+inline void mod_switch_to_next_inplace(const PhantomContext &context, PhantomCiphertext &encrypted,
+                                       const hip_stream_wrapper &stream_wrapper) {
+    encrypted = mod_switch_to_next(context, encrypted, stream_wrapper);
+}
+inline void mod_switch_to_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, size_t chain_index,
+                                  const hip_stream_wrapper &stream_wrapper) {
+    if (encrypted.chain_index() > chain_index) throw std::invalid_argument("cannot switch to higher level modulus");
+    while (encrypted.chain_index() != chain_index) mod_switch_to_next_inplace(context, encrypted, stream_wrapper);
+}
+
+
 // non-adjacent form of a rotation step (the reference falls back to it when no key exists for
 // the step itself, src/evaluate.cu:821-839)
 inline std::vector<int> naf(int value) {

@@ -114,6 +114,19 @@ int main() {
         rotate_inplace(context, rot3, 3, gk, sw);
         printf("{\"rotate3_naf\": \"%016llx\"}\n", (unsigned long long)fnv(download(rot3)));
 
+        // element-wise entry points (tests/add.cu-style): (a + b) - b', -a, mod_switch_to_next
+        {
+            PhantomCiphertext a = make_ct(context, moduli, 1, 57, 58, s), b = make_ct(context, moduli, 1, 67, 68, s);
+            add_inplace(context, a, b, sw);
+            printf("{\"add\": \"%016llx\"}\n", (unsigned long long)fnv(download(a)));
+            negate_inplace(context, a, sw);
+            sub_inplace(context, a, b, sw);
+            printf("{\"neg_sub\": \"%016llx\"}\n", (unsigned long long)fnv(download(a)));
+            mod_switch_to_inplace(context, a, 3, sw);
+            printf("{\"mod_switch_to_3\": \"%016llx\", \"ms_limbs\": %zu}\n", (unsigned long long)fnv(download(a)),
+                   a.coeff_modulus_size());
+        }
+
         // real keys: keygen -> encrypt -> HMult+relin -> decrypt (tests/relin.cu), all on the GPU.
         // Plaintexts are the constant polynomials 3*2^20 and 5*2^20 (in NTT form a constant is the
         // same residue in every slot), so the product must decrypt to 15*2^40 + small noise in

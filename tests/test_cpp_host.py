@@ -71,6 +71,13 @@ def test_cpp_host_layer_against_oracle(gpu, orc):
     assert res["rotate1"] == digest(rotate(ct(4, 37, 38), e1))
     # step 3 = NAF (-1, +4): applied in that order (least significant digit first)
     assert res["rotate3_naf"] == digest(rotate(rotate(ct(4, 47, 48), em1), e4))
+    a, b = ct(4, 57, 58), ct(4, 67, 68)
+    q = mods[:4][None, :, None]
+    add = (a + b) % q
+    assert res["add"] == digest(add)
+    ns = (2 * q - add - b) % q          # -(a+b) - b
+    assert res["neg_sub"] == digest(ns)
+    assert res["mod_switch_to_3"] == digest(ns[:, :2]) and res["ms_limbs"] == 2
     assert res["errors_caught"] == 5
     # keygen -> encrypt -> HMult+relin -> decrypt with real keys: product of the constants, small noise
     assert res["real_keys_rel_err"] < 1e-3 and res["real_keys_rest"] < 1e-3
