@@ -255,6 +255,16 @@ int pha_negate_rns_poly(pha_context *ctx, uint64_t *dst, const uint64_t *a, size
 int pha_mod_switch_drop_to_next(pha_context *ctx, size_t chain_index, const uint64_t *src, size_t cipher_size,
                                 uint64_t *dst, pha_stream_t stream);
 
+/* ---- CKKS encoder / decoder (PhantomCKKSEncoder, src/ckks.cu:130-283) ------
+ * values_host: interleaved (re, im) doubles on the HOST, like the reference's std::vector inputs;
+ * both calls synchronise the stream (the reference does, src/ckks.cu:187,282).
+ * encode: values_size <= sparse_slots <= N/2 (sparse_slots = 0: next power of two >= values_size)
+ * -> plain[l][N], NTT form, level chain_index; decode: the first sparse_slots slots of plain. */
+int pha_ckks_encode(pha_context *ctx, const double *values_host, size_t values_size, size_t sparse_slots,
+                    size_t chain_index, double scale, uint64_t *plain, pha_stream_t stream);
+int pha_ckks_decode(pha_context *ctx, const uint64_t *plain, size_t chain_index, double scale, size_t sparse_slots,
+                    double *values_host, pha_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

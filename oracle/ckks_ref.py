@@ -206,3 +206,35 @@ def negacyclic_mul(a, b):
         out[i] = d
         prod = (prod - d) >> bits
     return [out[i] - out[i + n] for i in range(n)]
+
+
+# ---- CKKS canonical-embedding encoder, by its definition (src/ckks.cu:130-283) -------------------
+def _slot_matrix(s):
+    """A[j][k] = xi^(5^j * k), xi = exp(2*pi*i / (4s)): decode is z = A u."""
+    m = 4 * s
+    rot = [pow(5, j, m) for j in range(s)]
+    e = np.array([[(r * k) % m for k in range(s)] for r in rot], dtype=np.float64)
+    return np.exp(2j * np.pi * e / m)
+
+
+def encode_ref(values, scale, n, sparse_slots):
+    """Integer coefficient vector (Python ints, length n) of the plaintext that PhantomCKKSEncoder
+    produces for `values` (zero-padded to sparse_slots): coefficients k*gap and (k+s)*gap are the
+    rounded real / imaginary parts of scale * u_k, u = A^-1 z = conj(A)^T z / s."""
+    s = sparse_slots
+    z = np.zeros(s, dtype=np.complex128)
+    z[:len(values)] = values
+    u = _slot_matrix(s).conj().T @ z / s
+    gap = n // (2 * s)
+    out = [0] * n
+    for k in range(s):
+        out[k * gap] = int(np.rint(scale * u[k].real))
+        out[(k + s) * gap] = int(np.rint(scale * u[k].imag))
+    return out
+
+
+def decode_ref(coeffs, scale, n, sparse_slots):
+    s = sparse_slots
+    gap = n // (2 * s)
+    u = np.array([complex(coeffs[k * gap] / scale, coeffs[(k + s) * gap] / scale) for k in range(s)])
+    return _slot_matrix(s) @ u

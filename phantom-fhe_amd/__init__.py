@@ -86,6 +86,8 @@ SIGNATURES = {
     "pha_multiply_rns_poly": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _vp]),
     "pha_negate_rns_poly": (_int, [_vp, _vp, _vp, _sz, _sz, _vp]),
     "pha_mod_switch_drop_to_next": (_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "pha_ckks_encode": (_int, [_vp, _vp, _sz, _sz, _sz, ctypes.c_double, _vp, _vp]),
+    "pha_ckks_decode": (_int, [_vp, _vp, _sz, ctypes.c_double, _sz, _vp, _vp]),
     "pha_lp_modup_begin": (_int, [_vp, _sz, _vp, _vp, _sz, _sz, _vp]),
     "pha_lp_modup_finish": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "pha_lp_key_switch_inner_prod": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
@@ -363,6 +365,21 @@ class PhantomContext:
     def mod_switch_to_next(self, chain_index, ct):
         out = self._empty(ct.shape[0], ct.shape[1] - 1)
         _check(lib().pha_mod_switch_drop_to_next(self._h, chain_index, _ptr(ct), ct.shape[0], _ptr(out), _stream()))
+        return out
+
+    # PhantomCKKSEncoder (include/ckks.h, src/ckks.cu:130-283) -------------------------------
+    def encode(self, values, scale, chain_index=1, sparse_slots=0):
+        """complex values (numpy) -> plaintext [l][N] device tensor in NTT form"""
+        v = np.ascontiguousarray(values, dtype=np.complex128)
+        plain = self._empty(self.level_limbs(chain_index))
+        _check(lib().pha_ckks_encode(self._h, v.ctypes.data, v.size, sparse_slots, chain_index, float(scale), _ptr(plain),
+                                     _stream()))
+        return plain
+
+    def decode(self, plain, scale, sparse_slots, chain_index=1):
+        out = np.zeros(sparse_slots, dtype=np.complex128)
+        _check(lib().pha_ckks_decode(self._h, _ptr(plain), chain_index, float(scale), sparse_slots, out.ctypes.data,
+                                     _stream()))
         return out
 
     # PhantomSecretKey (include/secretkey.h:150-290) ------------------------------------------

@@ -207,4 +207,40 @@ void build_level_constants(const std::vector<uint64_t> &moduli_QP, size_t size_P
         for (size_t k = 0; k < size_P; ++k) lc.moddown_matrix[j * size_P + k] = product_mod_except(P, 0, size_P, k, Q[j]);
 }
 
+// ---- multi-word helpers for the CRT tables ------------------------------------------------------
+static void mw_mul_word(std::vector<uint64_t> &a, uint64_t w) {  // a *= w, a has room
+    uint64_t carry = 0;
+    for (auto &x : a) {
+        const u128 p = static_cast<u128>(x) * w + carry;
+        x = static_cast<uint64_t>(p);
+        carry = static_cast<uint64_t>(p >> 64);
+    }
+}
+
+void build_crt_tables(const uint64_t *moduli, size_t l, CrtTables &t) {
+    t.l = l;
+    t.big_q.assign(l, 0);
+    t.big_q[0] = 1;
+    for (size_t j = 0; j < l; j++) mw_mul_word(t.big_q, moduli[j]);
+    t.qhat.assign(l * l, 0);
+    t.inv_qhat.assign(l, 0);
+    for (size_t j = 0; j < l; j++) {
+        std::vector<uint64_t> h(l, 0);
+        h[0] = 1;
+        for (size_t k = 0; k < l; k++)
+            if (k != j) mw_mul_word(h, moduli[k]);
+        std::copy(h.begin(), h.end(), t.qhat.begin() + j * l);
+        t.inv_qhat[j] = inv_mod_prime(product_mod_except(moduli, 0, l, j, moduli[j]), moduli[j]);
+    }
+    // (Q + 1) >> 1
+    t.half_q = t.big_q;
+    uint64_t carry = 1;
+    for (auto &x : t.half_q) {
+        const uint64_t s = x + carry;
+        carry = s < x ? 1 : 0;
+        x = s;
+    }
+    for (size_t i = 0; i < l; i++) t.half_q[i] = (t.half_q[i] >> 1) | (i + 1 < l ? t.half_q[i + 1] << 63 : 0);
+}
+
 }  // namespace pha

@@ -65,4 +65,15 @@ struct LevelConstants {
 };
 void build_level_constants(const std::vector<uint64_t> &moduli_QP, size_t size_P, size_t size_Ql, LevelConstants &lc);
 
+// CRT composition tables of the base q_0..q_{l-1} (src/util/rns.cu RNSBase::initialize, used by
+// compose_array src/rns_base.cu:236-402): multi-word little-endian integers of l words
+struct CrtTables {
+    size_t l = 0;
+    std::vector<uint64_t> big_q;        // [l]      Q = prod q_j
+    std::vector<uint64_t> half_q;       // [l]      (Q + 1) / 2: upper-half threshold (context_data.upper_half_threshold())
+    std::vector<uint64_t> qhat;         // [l][l]   Q / q_j
+    std::vector<uint64_t> inv_qhat;     // [l]      (Q / q_j)^-1 mod q_j
+};
+void build_crt_tables(const uint64_t *moduli, size_t l, CrtTables &t);
+
 }  // namespace pha

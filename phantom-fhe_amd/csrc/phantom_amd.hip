@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -18,6 +19,7 @@
 #include "numth.hpp"
 #include "rns_kernels.cuh"
 #include "keygen_kernels.cuh"
+#include "encoder_kernels.cuh"
 
 using namespace pha;
 
@@ -127,6 +129,13 @@ struct pha_context {
     std::map<uint32_t, std::unique_ptr<DevBuf<uint32_t>>> galois_tables;
     DevBuf<uint64_t> workspace;
     DevBuf<uint64_t> d_bigP_mod_q;  // key level, [size_Q] (key generation)
+    // CKKS encoder: rotation group 5^j mod 2N and per-level CRT composition tables
+    struct EncoderLevel {
+        DevBuf<uint64_t> big_q, half_q, qhat, inv_qhat;
+        int total_bits = 0;  // bit count of prod q_j (total_coeff_modulus_bit_count)
+    };
+    DevBuf<uint32_t> d_rot_group;
+    std::map<size_t, std::unique_ptr<EncoderLevel>> enc_levels;
 
     NttTables fwd_tables() const {
         return NttTables{d_mod.p, d_tw.p, d_twD.p, d_n_inv.p, d_n_inv_shoup.p, static_cast<uint32_t>(log_n), twD_stride,
@@ -782,6 +791,53 @@ int do_kswitch_key(pha_context *ctx, const uint64_t *sk, const uint64_t *new_key
     return PHA_OK;
 }
 
+// ---- CKKS encoder (src/ckks.cu:130-283) ---------------------------------------
+int get_encoder_level(pha_context *ctx, size_t limbs, pha_context::EncoderLevel **out) {
+    if (!ctx->d_rot_group.p) {
+        std::vector<uint32_t> rot(ctx->n / 4 ? ctx->n / 4 : 1);
+        uint32_t pos = 1;
+        for (auto &r : rot) {
+            r = pos;
+            pos = (pos * 5u) & static_cast<uint32_t>(2 * ctx->n - 1);
+        }
+        HIP_TRY(ctx->d_rot_group.upload(rot));
+    }
+    auto it = ctx->enc_levels.find(limbs);
+    if (it == ctx->enc_levels.end()) {
+        if (limbs > static_cast<size_t>(kMaxCrtWords)) return fail(PHA_ERR_INVALID_ARGUMENT, "too many limbs for the encoder");
+        CrtTables t;
+        build_crt_tables(ctx->moduli.data(), limbs, t);
+        auto lv = std::make_unique<pha_context::EncoderLevel>();
+        HIP_TRY(lv->big_q.upload(t.big_q));
+        HIP_TRY(lv->half_q.upload(t.half_q));
+        HIP_TRY(lv->qhat.upload(t.qhat));
+        HIP_TRY(lv->inv_qhat.upload(t.inv_qhat));
+        size_t top = limbs - 1;
+        while (top > 0 && t.big_q[top] == 0) top--;
+        lv->total_bits = static_cast<int>(64 * top + (64 - __builtin_clzll(t.big_q[top])));
+        it = ctx->enc_levels.emplace(limbs, std::move(lv)).first;
+    }
+    *out = it->second.get();
+    return PHA_OK;
+}
+
+int check_slots(const pha_context *ctx, size_t s) {
+    if (s < 2) return fail(PHA_ERR_INVALID_ARGUMENT, "single value encoding is not available");
+    if ((s & (s - 1)) || s > ctx->n / 2) return fail(PHA_ERR_INVALID_ARGUMENT, "sparse_slots must be a power of two <= N/2");
+    return PHA_OK;
+}
+
+template <bool INVERSE>
+void special_fft_stages(pha_context *ctx, double2 *v, uint32_t s, hipStream_t st) {
+    const dim3 grid((s / 2 + 255) / 256);
+    if (!INVERSE)
+        for (uint32_t len = 2; len <= s; len <<= 1)
+            hipLaunchKernelGGL((special_fft_stage_kernel<false>), grid, dim3(256), 0, st, v, ctx->d_rot_group.p, s, len);
+    else
+        for (uint32_t len = s; len >= 2; len >>= 1)
+            hipLaunchKernelGGL((special_fft_stage_kernel<true>), grid, dim3(256), 0, st, v, ctx->d_rot_group.p, s, len);
+}
+
 int get_galois_table(pha_context *ctx, uint32_t elt, const uint32_t **out) {
     if (!(elt & 1) || elt >= 2 * ctx->n) return fail(PHA_ERR_INVALID_ARGUMENT, "Galois element is not valid");
     auto it = ctx->galois_tables.find(elt);
@@ -1390,6 +1446,90 @@ int pha_mod_switch_drop_to_next(pha_context *ctx, size_t chain_index, const uint
     const size_t l = ctx->size_Q - (chain_index - 1), n = ctx->n;
     HIP_TRY(hipMemcpy2DAsync(dst, (l - 1) * n * sizeof(uint64_t), src, l * n * sizeof(uint64_t), (l - 1) * n * sizeof(uint64_t),
                              cipher_size, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return PHA_OK;
+}
+
+// ---- CKKS encoder / decoder (src/ckks.cu:130-283) ----------------------------------------------
+int pha_ckks_encode(pha_context *ctx, const double *values_host, size_t values_size, size_t sparse_slots, size_t chain_index,
+                    double scale, uint64_t *plain, pha_stream_t stream) {
+    REQUIRE_CTX(plain && (values_host || values_size == 0));
+    size_t limbs;
+    PHA_TRY(level_limbs(ctx, chain_index, &limbs));
+    if (values_size > ctx->n / 2) return fail(PHA_ERR_INVALID_ARGUMENT, "values_size is too large");
+    pha_context::EncoderLevel *lv;
+    PHA_TRY(get_encoder_level(ctx, limbs, &lv));
+    if (!(scale > 0) || static_cast<int>(std::log2(scale)) + 1 >= lv->total_bits)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "scale out of bounds");
+    size_t s = sparse_slots;
+    if (s == 0)
+        for (s = 1; s < values_size; s <<= 1) {}
+    PHA_TRY(check_slots(ctx, s));
+    if (values_size > s) return fail(PHA_ERR_INVALID_ARGUMENT, "values_size exceeds sparse_slots");
+    hipStream_t st = as_stream(stream);
+    const uint32_t n = static_cast<uint32_t>(ctx->n), S = static_cast<uint32_t>(s);
+    uint32_t log_s = 0;
+    while ((1u << log_s) < S) log_s++;
+    uint64_t *ws;
+    PHA_TRY(ensure_workspace(ctx, 4 * s + 2, &ws));
+    double2 *buf = reinterpret_cast<double2 *>(ws), *tmp = buf + s;
+    unsigned long long *d_max = reinterpret_cast<unsigned long long *>(tmp + s);
+    HIP_TRY(hipMemsetAsync(buf, 0, s * sizeof(double2), st));
+    if (values_size) HIP_TRY(hipMemcpyAsync(buf, values_host, values_size * sizeof(double2), hipMemcpyHostToDevice, st));
+    // u = (scale / s) * bitrev(stages(z)): inverse special FFT
+    special_fft_stages<true>(ctx, buf, S, st);
+    hipLaunchKernelGGL(bit_reverse_scale_kernel, dim3((S + 255) / 256), dim3(256), 0, st, tmp, buf, S, S, log_s,
+                       scale / static_cast<double>(s));
+    HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(max_abs_kernel, dim3((S + 255) / 256), dim3(256), 0, st, tmp, S, d_max);
+    PHA_TRY(check_launch("special fft"));
+    unsigned long long max_bits = 0;
+    HIP_TRY(hipMemcpyAsync(&max_bits, d_max, sizeof(max_bits), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    double max_coeff;
+    memcpy(&max_coeff, &max_bits, sizeof(double));
+    // one extra bit for the sign (src/ckks.cu:196-203)
+    const int max_coeff_bit_count = static_cast<int>(std::ceil(std::log2(std::max(max_coeff, 1.0)))) + 1;
+    if (!(max_coeff == max_coeff) || max_coeff_bit_count >= lv->total_bits)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "encoded values are too large");
+    HIP_TRY(hipMemsetAsync(plain, 0, limbs * n * sizeof(uint64_t), st));
+    hipLaunchKernelGGL(ckks_decompose_kernel, dim3((2 * S + 255) / 256), dim3(256), 0, st, plain, tmp, ctx->d_mod.p,
+                       static_cast<uint32_t>(limbs), n, S, n / (2 * S));
+    PHA_TRY(check_launch("ckks_decompose"));
+    NttRange r;
+    PHA_TRY(make_range(ctx, limbs, 0, 0, 0, 0, 0, r));
+    return ntt_forward(ctx, plain, 1, 0, r, EPI_NONE, Epilogue{}, st);
+}
+
+int pha_ckks_decode(pha_context *ctx, const uint64_t *plain, size_t chain_index, double scale, size_t sparse_slots,
+                    double *values_host, pha_stream_t stream) {
+    REQUIRE_CTX(plain && values_host);
+    size_t limbs;
+    PHA_TRY(level_limbs(ctx, chain_index, &limbs));
+    pha_context::EncoderLevel *lv;
+    PHA_TRY(get_encoder_level(ctx, limbs, &lv));
+    if (!(scale > 0) || static_cast<int>(std::log2(scale)) >= lv->total_bits) return fail(PHA_ERR_INVALID_ARGUMENT, "scale out of bounds");
+    PHA_TRY(check_slots(ctx, sparse_slots));
+    hipStream_t st = as_stream(stream);
+    const uint32_t n = static_cast<uint32_t>(ctx->n), S = static_cast<uint32_t>(sparse_slots);
+    uint32_t log_s = 0;
+    while ((1u << log_s) < S) log_s++;
+    uint64_t *ws;
+    PHA_TRY(ensure_workspace(ctx, limbs * n + 4 * sparse_slots, &ws));
+    uint64_t *copy = ws;
+    double2 *buf = reinterpret_cast<double2 *>(ws + limbs * n), *tmp = buf + sparse_slots;
+    NttRange r;
+    PHA_TRY(make_range(ctx, limbs, 0, 0, 0, 0, 0, r));
+    PHA_TRY(ntt_backward(ctx, copy, plain, 1, 0, r, EPI_NONE, Epilogue{}, st));
+    int inv_exp;
+    const double inv_mant = std::frexp(1.0 / scale, &inv_exp);
+    hipLaunchKernelGGL(ckks_compose_kernel, dim3((2 * S + 63) / 64), dim3(64), 0, st, tmp, copy, ctx->d_mod.p, lv->big_q.p,
+                       lv->half_q.p, lv->qhat.p, lv->inv_qhat.p, static_cast<uint32_t>(limbs), n, S, n / (2 * S), inv_mant, inv_exp);
+    // z = stages(bitrev(u)): forward special FFT
+    hipLaunchKernelGGL(bit_reverse_scale_kernel, dim3((S + 255) / 256), dim3(256), 0, st, buf, tmp, S, S, log_s, 1.0);
+    special_fft_stages<false>(ctx, buf, S, st);
+    PHA_TRY(check_launch("ckks decode"));
+    HIP_TRY(hipMemcpyAsync(values_host, buf, sparse_slots * sizeof(double2), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return PHA_OK;
 }
 

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <complex>
 #include <cstdint>
 #include <cstdlib>
 #include <map>
@@ -245,6 +246,43 @@ public:
     void set_scale(double s) { scale_ = s; }
 };
 
+// ---- CKKS encoder (include/ckks.h, src/ckks.cu:130-283) ------------------------------------------
+class PhantomCKKSEncoder {
+    size_t slots_ = 0, sparse_slots_ = 0;
+
+public:
+    explicit PhantomCKKSEncoder(const PhantomContext &context) : slots_(context.poly_degree() >> 1) {}
+    size_t slot_count() const { return slots_; }
+    size_t sparse_slots() const { return sparse_slots_; }
+    void reset_sparse_slots() { sparse_slots_ = 0; }
+
+    // the first encode fixes sparse_slots (next power of two >= values.size()), like src/ckks.cu:150-158
+    void encode(const PhantomContext &context, const std::vector<std::complex<double>> &values, double scale,
+                PhantomPlaintext &destination, size_t chain_index, const hip_stream_wrapper &stream_wrapper) {
+        if (values.size() > slots_) throw std::invalid_argument("values_size is too large");
+        if (sparse_slots_ == 0)
+            for (sparse_slots_ = 1; sparse_slots_ < values.size(); sparse_slots_ <<= 1) {}
+        const hipStream_t &s = stream_wrapper.get_stream();
+        destination.resize(context.coeff_mod_size(chain_index), context.poly_degree(), s);
+        check(pha_ckks_encode(context.handle(), reinterpret_cast<const double *>(values.data()), values.size(), sparse_slots_,
+                              chain_index, scale, destination.data(), s));
+        destination.set_chain_index(chain_index);
+        destination.set_scale(scale);
+    }
+    void encode(const PhantomContext &context, const std::vector<double> &values, double scale, PhantomPlaintext &destination,
+                size_t chain_index, const hip_stream_wrapper &stream_wrapper) {
+        std::vector<std::complex<double>> c(values.begin(), values.end());
+        encode(context, c, scale, destination, chain_index, stream_wrapper);
+    }
+    void decode(const PhantomContext &context, const PhantomPlaintext &plain, std::vector<std::complex<double>> &destination,
+                const hip_stream_wrapper &stream_wrapper) {
+        if (sparse_slots_ == 0) throw std::logic_error("decode before any encode: sparse_slots unknown");
+        destination.resize(sparse_slots_);
+        check(pha_ckks_decode(context.handle(), plain.data(), plain.chain_index(), plain.scale(), sparse_slots_,
+                              reinterpret_cast<double *>(destination.data()), stream_wrapper.get_stream()));
+    }
+};
+
 // ---- secret key (include/secretkey.h:150-290, src/secretkey.cu) -----------------------------------
 // Randomness: the reference seeds every draw from std::random_device; here one 64-bit seed given
 // at construction (default: std::random_device) determines every later draw, so runs can be
@@ -280,6 +318,8 @@ public:
     explicit PhantomSecretKey(const PhantomContext &context, uint64_t seed = (uint64_t(std::random_device{}()) << 32) ^ std::random_device{}())
         : seed_(seed) {
         gen_secretkey(context, nullptr);
+        // generated on the null stream; callers go on to use their own (non-blocking) streams
+        check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize");
     }
     PhantomSecretKey(PhantomSecretKey &&) = default;
     uint64_t *secret_key_array() const { return sk_.get(); }

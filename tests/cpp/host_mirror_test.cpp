@@ -5,6 +5,7 @@
 // FNV-1a digests and compared with the oracle by tests/test_cpp_host.py.
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <cstring>
 
@@ -161,6 +162,31 @@ int main() {
             int twice = 0;
             try { sk.gen_secretkey(context, s); } catch (const std::logic_error &) { twice = 1; }
             printf("{\"gen_twice_throws\": %d}\n", twice);
+        }
+
+        // encoder round trip through ciphertext arithmetic: (z1 + z2) * z1 slot-wise (tests/multi.cu)
+        {
+            PhantomSecretKey sk(context, 777);
+            PhantomRelinKey rk = sk.gen_relinkey(context, sw);
+            PhantomCKKSEncoder enc(context);
+            std::vector<std::complex<double>> z1(n / 2), z2(n / 2), out;
+            for (size_t i = 0; i < n / 2; i++) {
+                z1[i] = {std::cos(0.001 * i), 0.3 * std::sin(0.002 * i)};
+                z2[i] = {0.5 - 0.0001 * i, 0.25};
+            }
+            PhantomPlaintext p1, p2, dec;
+            enc.encode(context, z1, 1073741824.0, p1, 1, sw);
+            enc.encode(context, z2, 1073741824.0, p2, 1, sw);
+            PhantomCiphertext c1, c2;
+            sk.encrypt_symmetric(context, p1, c1, sw);
+            sk.encrypt_symmetric(context, p2, c2, sw);
+            add_inplace(context, c2, c1, sw);
+            multiply_and_relin_inplace(context, c2, c1, rk, sw);
+            sk.decrypt(context, c2, dec, sw);
+            enc.decode(context, dec, out, sw);
+            double err = 0;
+            for (size_t i = 0; i < n / 2; i++) err = std::max(err, std::abs(out[i] - (z1[i] + z2[i]) * z1[i]));
+            printf("{\"encoder_pipeline_err\": %.3e}\n", err);
         }
 
         // error behaviour of the reference

@@ -82,3 +82,4 @@ def test_cpp_host_layer_against_oracle(gpu, orc):
     # keygen -> encrypt -> HMult+relin -> decrypt with real keys: product of the constants, small noise
     assert res["real_keys_rel_err"] < 1e-3 and res["real_keys_rest"] < 1e-3
     assert res["gen_twice_throws"] == 1
+    assert res["encoder_pipeline_err"] < 1e-4
