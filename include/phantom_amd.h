@@ -265,6 +265,19 @@ int pha_ckks_encode(pha_context *ctx, const double *values_host, size_t values_s
 int pha_ckks_decode(pha_context *ctx, const uint64_t *plain, size_t chain_index, double scale, size_t sparse_slots,
                     double *values_host, pha_stream_t stream);
 
+/* ---- hoisted rotations ---------------------------------------------------------------------
+ * No counterpart in the reference (its *_hoisting drivers, src/boot/Bootstrapper.cu:1988-2055,
+ * rotate one at a time): n_rot Galois elements applied to ONE ciphertext ct[2][l][N] share the
+ * modup of c1 — per rotation only the inner product (with the automorphism applied to t_mod_up on
+ * the fly), the moddown and the permutation of c0 remain.  out_host[r][2][l][N] decrypts like
+ * pha_apply_galois_inplace(ct, galois_elts_host[r]) but is not bit-identical to it (the base
+ * extension commutes with the automorphism only up to multiples of Q; oracle.c "Hoisted
+ * rotations").  galois_elts_host, evks_host (device pointer arrays as in pha_keyswitch_inplace,
+ * one per rotation) and out_host are HOST arrays; outputs must not alias ct. */
+int pha_rotate_hoisted(pha_context *ctx, size_t chain_index, const uint64_t *ct, size_t n_rot,
+                       const uint32_t *galois_elts_host, const uint64_t *const *const *evks_host,
+                       uint64_t *const *out_host, pha_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,8 @@ def lib():
             "orc_generate_one_kswitch_key": (None, [_vp, _u64p, _u64p, _u64, ctypes.POINTER(_u64p)]),
             "orc_gen_relinkey": (None, [_vp, _u64p, _u64, ctypes.POINTER(_u64p)]),
             "orc_gen_galois_key": (None, [_vp, _u64p, _u32, _u64, ctypes.POINTER(_u64p)]),
+            "orc_rotate_hoisted": (None, [_vp, _sz, _u64p, _sz, _u32p, ctypes.POINTER(ctypes.POINTER(_u64p)),
+                                          ctypes.POINTER(_u64p)]),
             "orc_fnv1a64": (_u64, [_u64p, _sz]),
             "orc_fill_uniform": (None, [_u64p, _sz, _u64, _u64]),
         }
@@ -249,6 +251,17 @@ class Oracle:
         res = np.zeros((3, limbs, self.n), dtype=np.uint64)
         lib().orc_tensor_prod_2x2(self._h, p(np.ascontiguousarray(op1)), p(np.ascontiguousarray(op2)), limbs, p(res))
         return res
+
+    def rotate_hoisted(self, size_ql, ct, elts, evks):
+        """rotations of ONE ciphertext by several Galois elements sharing the modup (oracle.c)"""
+        ct = np.ascontiguousarray(ct)
+        outs = [np.zeros((2, size_ql, self.n), dtype=np.uint64) for _ in elts]
+        e = np.ascontiguousarray(elts, dtype=np.uint32)
+        keys = [self._evk_ptrs(k) for k in evks]
+        karr = (ctypes.POINTER(_u64p) * len(keys))(*keys)
+        oarr = (_u64p * len(outs))(*[p(o) for o in outs])
+        lib().orc_rotate_hoisted(self._h, size_ql, p(ct), len(elts), e.ctypes.data_as(_u32p), karr, oarr)
+        return outs
 
     # ---- key generation / encryption / decryption (oracle.c "Key generation") ---------------
     def level_limbs(self, chain_index):

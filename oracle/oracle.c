@@ -857,3 +857,34 @@ void orc_gen_galois_key(const orc_ctx *c, const uint64_t *sk, uint32_t galois_el
     orc_generate_one_kswitch_key(c, sk, sg, seed, evks);
     free(sg);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Hoisted rotations: several Galois elements applied to ONE ciphertext share the modup of c1.
+ * No counterpart in the reference (its *_hoisting drivers, src/boot/Bootstrapper.cu:1988-2055,
+ * still rotate one at a time with rotate_vector); the algorithm is the standard one: the
+ * automorphism commutes with the digit decomposition and base extension up to a multiple of Q
+ * per coefficient (the same kind of term the uncorrected fast base conversion already carries),
+ * so   rot_g(ct) = (sigma_g(c0), 0) + moddown( <sigma_g(modup(c1)), evk_g> ),
+ * sigma_g acting on NTT-form limbs as the index permutation of apply_galois_ntt.  Results
+ * decrypt like apply_galois_inplace's but are not bit-identical to it.
+ * ct [2][size_Ql][n]; out[r] [2][size_Ql][n]; evks[r]: the key of elts[r].
+ * ---------------------------------------------------------------------------------------- */
+void orc_rotate_hoisted(const orc_ctx *c, size_t size_Ql, const uint64_t *ct, size_t n_rot, const uint32_t *elts,
+                        const uint64_t *const *const *evks, uint64_t *const *out) {
+    const size_t n = c->n, size_QlP = size_Ql + c->size_P, beta = level_beta(c, size_Ql);
+    uint64_t *t = (uint64_t *)malloc(beta * size_QlP * n * sizeof(uint64_t));
+    uint64_t *tg = (uint64_t *)malloc(beta * size_QlP * n * sizeof(uint64_t));
+    uint64_t *cx = (uint64_t *)malloc(2 * size_QlP * n * sizeof(uint64_t));
+    orc_modup(c, size_Ql, t, ct + size_Ql * n);
+    for (size_t r = 0; r < n_rot; r++) {
+        orc_apply_galois_ntt(c->log_n, t, beta * size_QlP, elts[r], tg);
+        orc_key_switch_inner_prod(c, size_Ql, cx, tg, evks[r]);
+        for (int i = 0; i < 2; i++) orc_moddown_from_ntt(c, size_Ql, cx + (size_t)i * size_QlP * n, cx + (size_t)i * size_QlP * n);
+        orc_apply_galois_ntt(c->log_n, ct, size_Ql, elts[r], out[r]);
+        memset(out[r] + size_Ql * n, 0, size_Ql * n * sizeof(uint64_t));
+        for (int i = 0; i < 2; i++) orc_add_to_ct(c, size_Ql, out[r] + (size_t)i * size_Ql * n, cx + (size_t)i * size_QlP * n);
+    }
+    free(t);
+    free(tg);
+    free(cx);
+}

@@ -104,6 +104,8 @@ void orc_ckks_decrypt(const orc_ctx *c, const uint64_t *sk, const uint64_t *ct, 
 void orc_generate_one_kswitch_key(const orc_ctx *c, const uint64_t *sk, const uint64_t *new_key, uint64_t seed,
                                   uint64_t *const *evks);
 void orc_gen_relinkey(const orc_ctx *c, const uint64_t *sk, uint64_t seed, uint64_t *const *evks);
+void orc_rotate_hoisted(const orc_ctx *c, size_t size_Ql, const uint64_t *ct, size_t n_rot, const uint32_t *elts,
+                        const uint64_t *const *const *evks, uint64_t *const *out);
 void orc_gen_galois_key(const orc_ctx *c, const uint64_t *sk, uint32_t galois_elt, uint64_t seed, uint64_t *const *evks);
 
 #ifdef __cplusplus

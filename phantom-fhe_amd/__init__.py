@@ -88,6 +88,7 @@ SIGNATURES = {
     "pha_mod_switch_drop_to_next": (_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "pha_ckks_encode": (_int, [_vp, _vp, _sz, _sz, _sz, ctypes.c_double, _vp, _vp]),
     "pha_ckks_decode": (_int, [_vp, _vp, _sz, ctypes.c_double, _sz, _vp, _vp]),
+    "pha_rotate_hoisted": (_int, [_vp, _sz, _vp, _sz, _u32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
     "pha_lp_modup_begin": (_int, [_vp, _sz, _vp, _vp, _sz, _sz, _vp]),
     "pha_lp_modup_finish": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "pha_lp_key_switch_inner_prod": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
@@ -429,6 +430,16 @@ class PhantomContext:
         digits, arr = self._new_evk()
         _check(lib().pha_gen_galois_key(self._h, _ptr(sk), galois_elt, seed, arr, _stream()))
         return EvalKey(digits)
+
+    def rotate_hoisted(self, chain_index, ct, galois_elts, galois_keys):
+        """Rotations of ONE ciphertext by several Galois elements sharing the modup; returns the list of
+        rotated ciphertexts (include/phantom_amd.h "hoisted rotations")."""
+        outs = [self._empty(2, ct.shape[1]) for _ in galois_elts]
+        elts = (_u32 * len(galois_elts))(*galois_elts)
+        keys = (_vp * len(galois_keys))(*[k.ptr for k in galois_keys])
+        out_ptrs = (_vp * len(outs))(*[o.data_ptr() for o in outs])
+        _check(lib().pha_rotate_hoisted(self._h, chain_index, _ptr(ct), len(outs), elts, keys, out_ptrs, _stream()))
+        return outs
 
     # limb-parallel steps (include/phantom_amd.h "limb-parallel key switch"); w = (q_begin, q_count,
     # p_begin, p_count), orchestrated by limb_parallel.LimbParallelEvaluator ------------------

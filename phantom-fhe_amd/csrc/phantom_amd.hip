@@ -473,13 +473,13 @@ int do_modup(pha_context *ctx, LevelTool *lt, uint64_t *dst, const uint64_t *cks
 }
 
 int do_inner_prod(pha_context *ctx, LevelTool *lt, uint64_t *cx, const uint64_t *t_mod_up, const uint64_t *const *evks,
-                  hipStream_t st) {
+                  hipStream_t st, const uint32_t *perm = nullptr) {
     const uint32_t n = static_cast<uint32_t>(ctx->n);
     const uint32_t size_QlP = static_cast<uint32_t>(lt->size_Ql + ctx->size_P);
     hipLaunchKernelGGL(key_switch_inner_prod_kernel, dim3(size_QlP * (n / 512)), dim3(256), 0, st, cx, t_mod_up, evks,
                        ctx->d_mod.p, n, static_cast<uint32_t>(ctx->size_QP), size_QlP,
                        static_cast<uint32_t>(ctx->size_Q), static_cast<uint32_t>(lt->size_Ql),
-                       static_cast<uint32_t>(lt->beta), 0u);
+                       static_cast<uint32_t>(lt->beta), 0u, perm);
     return check_launch("key_switch_inner_prod");
 }
 
@@ -1530,6 +1530,30 @@ int pha_ckks_decode(pha_context *ctx, const uint64_t *plain, size_t chain_index,
     PHA_TRY(check_launch("ckks decode"));
     HIP_TRY(hipMemcpyAsync(values_host, buf, sparse_slots * sizeof(double2), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return PHA_OK;
+}
+
+// ---- hoisted rotations (no counterpart in the reference; see oracle.c "Hoisted rotations") ------
+int pha_rotate_hoisted(pha_context *ctx, size_t chain_index, const uint64_t *ct, size_t n_rot, const uint32_t *galois_elts_host,
+                       const uint64_t *const *const *evks_host, uint64_t *const *out_host, pha_stream_t stream) {
+    REQUIRE_CTX(ct && galois_elts_host && evks_host && out_host);
+    LevelTool *lt;
+    PHA_TRY(get_level(ctx, chain_index, &lt));
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, size_QlP = size_Ql + ctx->size_P;
+    hipStream_t st = as_stream(stream);
+    uint64_t *ws;
+    PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n, &ws));
+    uint64_t *t_mod_up = ws, *cx = t_mod_up + lt->beta * size_QlP * n, *scratch = cx + 2 * size_QlP * n;
+    PHA_TRY(do_modup(ctx, lt, t_mod_up, ct + size_Ql * n, scratch, st));  // once for every rotation
+    for (size_t r = 0; r < n_rot; r++) {
+        if (!out_host[r] || !evks_host[r] || out_host[r] == ct) return fail(PHA_ERR_INVALID_ARGUMENT, "null or aliasing rotation output");
+        const uint32_t *perm;
+        PHA_TRY(get_galois_table(ctx, galois_elts_host[r], &perm));
+        PHA_TRY(do_inner_prod(ctx, lt, cx, t_mod_up, evks_host[r], st, perm));
+        PHA_TRY(do_galois(ctx, ct, size_Ql, perm, out_host[r], st));
+        HIP_TRY(hipMemsetAsync(out_host[r] + size_Ql * n, 0, size_Ql * n * sizeof(uint64_t), st));
+        PHA_TRY(do_moddown(ctx, lt, out_host[r], cx, scratch, out_host[r], 2, st));
+    }
     return PHA_OK;
 }
 

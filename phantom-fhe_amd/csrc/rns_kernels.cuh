@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void key_switch_inner_prod_kernel(uint64_t *ds
                                                                     const uint64_t *const *evks, const DModulus *mod,
                                                                     uint32_t n, uint32_t size_QP, uint32_t size_QlP,
                                                                     uint32_t size_Q, uint32_t size_Ql, uint32_t beta,
-                                                                    uint32_t limb0) {
+                                                                    uint32_t limb0, const uint32_t *perm = nullptr) {
     const uint32_t per_limb = n / 512;
     const uint32_t nid = limb0 + blockIdx.x / per_limb;  // limbs [limb0, limb0 + gridDim.x / per_limb)
     const uint32_t k = ((blockIdx.x % per_limb) * 256 + threadIdx.x) * 2;
@@ -173,7 +173,14 @@ __global__ __launch_bounds__(256) void key_switch_inner_prod_kernel(uint64_t *ds
     const size_t size_QlP_n = static_cast<size_t>(size_QlP) * n, size_QP_n = static_cast<size_t>(size_QP) * n;
     u128_t a0x = {0, 0}, a0y = {0, 0}, a1x = {0, 0}, a1y = {0, 0};
     for (uint32_t d = 0; d < beta; d++) {
-        const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(t_mod_up + d * size_QlP_n + c2_id);
+        ulonglong2 t;
+        if (perm == nullptr) {
+            t = *reinterpret_cast<const ulonglong2 *>(t_mod_up + d * size_QlP_n + c2_id);
+        } else {  // hoisted rotation: the automorphism is applied to t_mod_up on the fly (index gather)
+            const uint64_t *row = t_mod_up + d * size_QlP_n + static_cast<size_t>(nid) * n;
+            t.x = row[perm[k]];
+            t.y = row[perm[k + 1]];
+        }
         const uint64_t *evk = evks[d];
         const ulonglong2 e0 = *reinterpret_cast<const ulonglong2 *>(evk + evk_id);
         const ulonglong2 e1 = *reinterpret_cast<const ulonglong2 *>(evk + size_QP_n + evk_id);

@@ -292,3 +292,31 @@ def test_keyswitch_60bit_primes_extreme_residues(gpu, pha, orc, size_p):
     ctx.modup(1, d_t, _dev(pha, c2))
     assert (_host(pha, d_t) == t_ref).all()
     ctx.close()
+
+
+@pytest.mark.parametrize("size_p,chain_index", [(2, 1), (2, 2), (1, 1), (3, 2)])
+def test_hoisted_rotations(gpu, pha, orc, size_p, chain_index):
+    """Several rotations of one ciphertext sharing the modup: bit-exact against the oracle's
+    restatement of the hoisted algorithm, and (real keys) decrypting to the rotated message."""
+    from oracle.ckks_ref import CkksHarness
+    mods = orc.coeff_modulus_create(4096, [50, 40, 40, 40, 40, 40] + [55] * size_p)
+    o = orc.Oracle(12, mods, size_p)
+    ctx = pha.PhantomContext(12, mods, size_p)
+    size_ql = o.size_Q - (chain_index - 1)
+    h = CkksHarness(o, seed=7)
+    delta = 1 << 36
+    msg = [int(v) * delta for v in np.random.default_rng(2).integers(-8, 9, size=4096)]
+    ct = h.encrypt(msg, size_ql)
+    elts = [orc.galois_elt_from_step(12, s) for s in (1, -3, 64)] + [2 * 4096 - 1]
+    keys_h = [h.galois_key(e) for e in elts]
+    keys_d = [pha.EvalKey([pha.to_device(k) for k in key]) for key in keys_h]
+    outs = ctx.rotate_hoisted(chain_index, pha.to_device(ct), elts, keys_d)
+    refs = o.rotate_hoisted(size_ql, ct, elts, keys_h)
+    for e, out, ref in zip(elts, outs, refs):
+        got = pha.to_host(out)
+        assert (got == ref).all()
+        err = max(abs(a - b) for a, b in zip(h.decrypt(got, size_ql), h.galois_coeffs(msg, e)))
+        assert err < delta * 1e-4
+    with pytest.raises(pha.PhantomError):
+        ctx.rotate_hoisted(chain_index, pha.to_device(ct), [4], keys_d[:1])   # even Galois element
+    ctx.close()
