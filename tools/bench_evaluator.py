@@ -44,6 +44,11 @@ def run(size_p=12, size_q=36):
     res["stage_moddown_x2_ms"] = t_ms(lambda: (ctx.moddown_from_NTT(1, cx[0], cx[0]), ctx.moddown_from_NTT(1, cx[1], cx[1])))
     res["stage_tensor_ms"] = t_ms(lambda: ctx.tensor_prod_2x2(ct1, ct2, size_q, ct1))
     res["stage_galois_ms"] = t_ms(lambda: ctx.apply_galois_ntt(ct2, 2 * size_q, 5, cx))
+    # 8 rotations of one ciphertext: one by one vs hoisted (shared modup)
+    elts = [pha.galois_elt_from_step(16, st) for st in range(1, 9)]
+    keys = [evk] * 8
+    res["rotate_x8_ms"] = t_ms(lambda: [ctx.apply_galois_inplace(1, ct2, e, evk) for e in elts], reps=10)
+    res["rotate_x8_hoisted_ms"] = t_ms(lambda: ctx.rotate_hoisted(1, ct2, elts, keys), reps=10)
     res["config"] = {"N": N, "size_Q": size_q, "size_P": size_p, "dnum": dnum}
     ctx.close()
     return res
