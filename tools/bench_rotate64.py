@@ -21,7 +21,13 @@ def main():
     rank, world, local_rank, dist = bench.dist_setup("nccl")
     torch.cuda.set_device(local_rank)
     mods = pha.coeff_modulus_create(N, [60] + [50] * (SIZE_Q - 1) + [60] * SIZE_P)
-    ctx = pha.PhantomContext(16, mods, SIZE_P)
+    # STREAMS > 1: independent ciphertexts go round-robin to that many (context, stream) pairs, so that
+    # the latency-bound small launches of one key switch overlap with another's (each context owns its
+    # workspace; contexts are not shared between streams)
+    n_streams = int(os.environ.get("STREAMS", "2"))
+    ctxs = [pha.PhantomContext(16, mods, SIZE_P) for _ in range(n_streams)]
+    streams = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream()]
+    ctx = ctxs[0]
     lo, hi = bench.shard_units(TOTAL, world, rank)
     g = torch.Generator(device="cuda").manual_seed(100 + rank)
     small = int(mods.min())
@@ -31,8 +37,9 @@ def main():
     elt = pha.galois_elt_from_step(16, 1)
 
     def step():
-        for ct in cts:
-            ctx.apply_galois_inplace(1, ct, elt, evk)
+        for i, ct in enumerate(cts):
+            with torch.cuda.stream(streams[i % n_streams]):
+                ctxs[i % n_streams].apply_galois_inplace(1, ct, elt, evk)
 
     def barrier():
         torch.cuda.synchronize()
@@ -50,8 +57,9 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "CKKS rotate, 64 independent ciphertexts (N=2^16, 36+12 limbs, dnum=3)",
                           "value": TOTAL * steps / el, "unit": "ciphertexts/s", "ms_per_64": 1e3 * el / steps,
-                          "n_gpus": world, "steps": steps, "scaling": "strong", "data": "synthetic"}), flush=True)
-    ctx.close()
+                          "n_gpus": world, "steps": steps, "streams": n_streams, "scaling": "strong", "data": "synthetic"}), flush=True)
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
