@@ -278,6 +278,16 @@ int pha_rotate_hoisted(pha_context *ctx, size_t chain_index, const uint64_t *ct,
                        const uint32_t *galois_elts_host, const uint64_t *const *const *evks_host,
                        uint64_t *const *out_host, pha_stream_t stream);
 
+/* ---- bootstrapping primitives -----------------------------------------------
+ * Bootstrapper::modraise_inplace (src/boot/Bootstrapper.cu:2801-2861): src[2][1][N], a ciphertext at
+ * the lowest level (one limb, NTT form) -> dst[2][size_Q][N] at the top level (chain_index 1),
+ * every coefficient lifted to its centred representative modulo q0 */
+int pha_mod_raise(pha_context *ctx, const uint64_t *src, uint64_t *dst, pha_stream_t stream);
+/* gen_secretkey with parms.secret_key_hamming_weight (src/secretkey.cu:401-433): exactly
+ * hamming_weight coefficients are +-1; seeded like pha_gen_secretkey */
+int pha_gen_secretkey_sparse(pha_context *ctx, uint64_t seed, size_t hamming_weight, uint64_t *sk,
+                             pha_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,8 @@ SIGNATURES = {
     "pha_ckks_encode": (_int, [_vp, _vp, _sz, _sz, _sz, ctypes.c_double, _vp, _vp]),
     "pha_ckks_decode": (_int, [_vp, _vp, _sz, ctypes.c_double, _sz, _vp, _vp]),
     "pha_rotate_hoisted": (_int, [_vp, _sz, _vp, _sz, _u32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
+    "pha_mod_raise": (_int, [_vp, _vp, _vp, _vp]),
+    "pha_gen_secretkey_sparse": (_int, [_vp, _u64, _sz, _vp, _vp]),
     "pha_lp_modup_begin": (_int, [_vp, _sz, _vp, _vp, _sz, _sz, _vp]),
     "pha_lp_modup_finish": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "pha_lp_key_switch_inner_prod": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
@@ -391,10 +393,19 @@ class PhantomContext:
         import torch
         return torch.empty((*shape, self.n), dtype=torch.int64, device="cuda")
 
-    def gen_secretkey(self, seed):
+    def gen_secretkey(self, seed, hamming_weight=0):
         sk = self._empty(self.size_QP)
-        _check(lib().pha_gen_secretkey(self._h, seed, _ptr(sk), _stream()))
+        if hamming_weight:
+            _check(lib().pha_gen_secretkey_sparse(self._h, seed, hamming_weight, _ptr(sk), _stream()))
+        else:
+            _check(lib().pha_gen_secretkey(self._h, seed, _ptr(sk), _stream()))
         return sk
+
+    def mod_raise(self, ct):
+        """ct [2][1][N] at the lowest level -> [2][size_Q][N] at chain_index 1 (Bootstrapper::modraise_inplace)"""
+        out = self._empty(2, self.size_Q)
+        _check(lib().pha_mod_raise(self._h, _ptr(ct), _ptr(out), _stream()))
+        return out
 
     def encrypt_zero_symmetric(self, sk, chain_index, seed_a, seed_e):
         ct = self._empty(2, self.level_limbs(chain_index))

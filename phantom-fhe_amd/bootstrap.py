@@ -1,0 +1,244 @@
+"""CKKS bootstrapping for sparsely packed ciphertexts over the evaluator interface of ckks.py
+(the reference's Bootstrapper::bootstrap_sparse*, src/boot/Bootstrapper.cu:2863-2934,
+and ModularReducer, src/boot/ModularReducer.cu).
+
+Pipeline (s = sparse slots, g = N/(2s), message polynomial m(Y), Y = X^g, at the one-limb level):
+
+    ModRaise      t(X) = m + q0*I(X) over the top level; the scale is re-declared as q0      (:2814-2868)
+    SubSum        log2(g) rotate-and-add steps project onto the subring: g*(m + q0*I')(Y)       (:2870-2876)
+    CoeffToSlot   one BSGS linear transform with conj(A)^T/(s*g*Kb) puts (coefficient_k +
+                  i*coefficient_{k+s}) / (q0*Kb) into slot k; real and imaginary parts are split
+                  with the conjugate (exact operations)
+    EvalMod       on both parts: Chebyshev interpolant of cos(2*pi*(Kb*w - 1/4) / 2^r) by a
+                  baby-step/giant-step evaluation with exact target scales, then r double angles:
+                  sin(2*pi*x) ~ 2*pi*(x - I) for x = m/q0 + I
+    SlotToCoeff   re + i*im recombined (exact), one BSGS linear transform with A/(2*pi)
+    the scale is re-declared so that the result decodes to the input message              (:2933)
+
+Differences from the reference, which a maintainer should know: the reference factors the two
+linear transforms FFT-style over several levels and takes its polynomial from a Remez
+approximation computed with NTL; here each transform is ONE dense s x s BSGS level (right for the
+sparse packings s <= 2^9 that bootstrap_sparse targets; baby steps use hoisted rotations) and the
+polynomial is the Chebyshev interpolant computed in double precision — no NTL, no files.
+"""
+import math
+
+import numpy as np
+
+
+def slot_matrix(s):
+    """A[j][k] = xi^(5^j k), xi = exp(2 pi i / 4s): slots = A @ (coeff_k + i coeff_{k+s})"""
+    m = 4 * s
+    rot = [pow(5, j, m) for j in range(s)]
+    e = np.array([[(r * k) % m for k in range(s)] for r in rot], dtype=np.float64)
+    return np.exp(2j * np.pi * e / m)
+
+
+class LinearTransform:
+    """z -> M z on the s sparse slots by baby-step/giant-step diagonals, one level.
+    M z = sum_g rot( sum_b rot(diag_{g*n1+b}, -g*n1) * rot(z, b), g*n1 )."""
+
+    def __init__(self, ev, matrix, level, diag_scale):
+        s = matrix.shape[0]
+        self.ev, self.s, self.level, self.diag_scale = ev, s, level, diag_scale
+        self.n1 = 1 << math.ceil(math.log2(s) / 2)
+        self.n2 = s // self.n1
+        j = np.arange(s)
+        self.diags = {}
+        for g in range(self.n2):
+            for b in range(self.n1):
+                d = g * self.n1 + b
+                diag = matrix[j, (j + d) % s]
+                if np.abs(diag).max() < 1e-300:
+                    continue
+                self.diags[(g, b)] = ev.encode(np.roll(diag, g * self.n1), diag_scale, level)
+
+    def steps(self):
+        return [b for b in range(1, self.n1)] + [g * self.n1 for g in range(1, self.n2)]
+
+    def apply(self, ct):
+        ev = self.ev
+        ct = ev.drop(ct, self.level)
+        babies = ev.rotate_many(ct, list(range(self.n1)))          # one hoisted modup for all baby steps
+        total = None
+        for g in range(self.n2):
+            inner = None
+            for b in range(self.n1):
+                pt = self.diags.get((g, b))
+                if pt is None:
+                    continue
+                term = ev.mul_plain(babies[b], pt)
+                inner = term if inner is None else ev.add(inner, term)
+            if inner is None:
+                continue
+            if g:
+                inner = ev.rotate(inner, g * self.n1)
+            total = inner if total is None else ev.add(total, inner)
+        return ev.rescale(total)
+
+
+class ChebyshevEvaluator:
+    """sum_j c_j T_j(w) with depth ceil(log2(d+1)) + 1 and exact scales: every addition joins
+    operands of identical (level, scale) because constants are encoded at the scale that makes the
+    rescaled product land on the target (Paterson-Stockmeyer over the Chebyshev basis:
+    p = q * T_h + r with T_j = 2 T_{j-h} T_h - T_{2h-j})."""
+
+    def __init__(self, ev, coeffs, baby_log=2):
+        self.ev = ev
+        self.c = np.array(coeffs, dtype=np.float64)
+        d = len(self.c) - 1
+        self.m = max(1, math.ceil(math.log2(d + 1)))
+        self.l = min(baby_log, self.m)
+        self.depth = self.m + 1
+
+    def _powers(self, w):
+        ev = self.ev
+        T = {1: w}
+        for j in range(2, 1 << self.l):          # babies T_2 .. T_{2^l - 1}
+            a = 1 << (j.bit_length() - 1)
+            T[j] = self._product(T, j // 2, j // 2) if j == a else self._product(T, a, j - a)
+        for k in range(self.l, self.m):          # giants T_{2^l} .. T_{2^(m-1)}
+            h = 1 << k
+            if h not in T:
+                T[h] = self._product(T, h // 2, h // 2)
+        return T
+
+    def _product(self, T, a, b):
+        """T_{a+b} = 2 T_a T_b - T_{|a-b|}"""
+        ev = self.ev
+        x, y = T[a], T[b]
+        lvl = max(x.level, y.level)
+        p = ev.rescale(ev.double(ev.mul(ev.drop(x, lvl), ev.drop(y, lvl))))
+        if a == b:
+            return ev.add_const(p, -1.0)
+        return ev.sub(p, ev.to_level_scale(T[abs(a - b)], p.level, p.scale))
+
+    def __call__(self, w, target_scale=None):
+        ev = self.ev
+        self.T = self._powers(w)
+        self.L0 = w.level
+        level = self.L0 + self.depth
+        scale = w.scale if target_scale is None else target_scale
+        return self._eval(self.c, self.m, level, scale)
+
+    def _leaf(self, c, level, scale):
+        """sum_j c_j T_j, j < 2^l, landing exactly on (level, scale)"""
+        ev = self.ev
+        lvl = level - 1
+        q = ev.q_last(lvl)
+        acc = None
+        for j in range(1, len(c)):
+            if abs(c[j]) < 1e-300:
+                continue
+            t = ev.drop(self.T[j], lvl)
+            term = ev.mul_const(t, c[j], scale * q / t.scale)
+            acc = term if acc is None else ev.add(acc, term)
+        if acc is None:
+            return None if abs(c[0]) < 1e-300 else ("const", c[0])
+        if abs(c[0]) >= 1e-300:
+            acc = ev.add_const(acc, c[0])
+        return ev.rescale(acc)
+
+    def _eval(self, c, k, level, scale):
+        ev = self.ev
+        c = np.trim_zeros(np.asarray(c, dtype=np.float64), "b")
+        if len(c) == 0:
+            return None
+        if k <= self.l or len(c) <= (1 << self.l):
+            return self._leaf(c[:1 << self.l] if len(c) > (1 << self.l) else c, level, scale)
+        h = 1 << (k - 1)
+        if len(c) <= h:
+            return self._eval(c, k - 1, level, scale)
+        # p = q*T_h + r
+        qc = np.zeros(len(c) - h)
+        r = np.array(c[:h], dtype=np.float64)
+        qc[0] = c[h]
+        for j in range(h + 1, len(c)):
+            qc[j - h] = 2.0 * c[j]
+            r[2 * h - j] -= c[j]
+        Th = ev.drop(self.T[h], level - 1)
+        qct = self._eval(qc, k - 1, level - 1, scale * ev.q_last(level - 1) / Th.scale)
+        rct = self._eval(r, k - 1, level, scale)
+        if isinstance(qct, tuple):       # q is a constant: q*T_h is a plaintext multiple of T_h
+            prod = ev.rescale(ev.mul_const(Th, qct[1], scale * ev.q_last(level - 1) / Th.scale))
+        elif qct is None:
+            prod = None
+        else:
+            prod = ev.rescale(ev.mul(qct, Th))
+        if prod is None:
+            return rct
+        if rct is None:
+            return prod
+        if isinstance(rct, tuple):
+            return ev.add_const(prod, rct[1])
+        return ev.add(prod, rct)
+
+
+class Bootstrapper:
+    """Sparse-slot bootstrapping.  Levels used: 1 (CoeffToSlot) + cheb.depth + r (EvalMod) + 1
+    (SlotToCoeff), starting from level 1 after the modulus raise.  The primes under the two linear
+    transforms should be large (the reference's parameter sets do the same) so that their
+    diagonals can be encoded precisely; the EvalMod primes should be close to the working scale."""
+
+    def __init__(self, ev, K=12, r=3, degree=31, delta=2.0 ** 40, baby_log=2):
+        self.ev, self.K, self.r, self.delta = ev, K, r, delta
+        s, n = ev.s, ev.n
+        self.s, self.g = s, n // (2 * s)
+        self.Kb = K + 0.5
+        # Chebyshev interpolant of f(w) = cos(2 pi (Kb w - 1/4) / 2^r) on [-1, 1]
+        f = lambda w: np.cos(2.0 * np.pi * (self.Kb * w - 0.25) / (1 << r))  # noqa: E731
+        self.cheb = ChebyshevEvaluator(ev, np.polynomial.chebyshev.chebinterpolate(f, degree), baby_log)
+        A = slot_matrix(s)
+        q0 = ev.q[0]
+        # level 1: diagonals at the scale that turns the re-declared scale q0 into delta after the rescale
+        c2s_scale = delta * ev.q_last(1) / q0
+        self.c2s = LinearTransform(ev, A.conj().T / (s * self.g * self.Kb * 2.0), 1, c2s_scale)
+        self.evalmod_level = 2
+        self.s2c_level = 2 + self.cheb.depth + r
+        # scale of the EvalMod output: delta after the polynomial, squared and rescaled by every double angle
+        sv, lvl = delta, 2 + self.cheb.depth
+        for _ in range(r):
+            sv, lvl = sv * sv / ev.q_last(lvl), lvl + 1
+        # A/(2 pi) undoes the sine's factor, q0/delta brings the message back from units of q0 to the
+        # working scale: the output is a ciphertext of scale delta again
+        self.s2c = LinearTransform(ev, A * (q0 / delta) / (2.0 * np.pi), self.s2c_level,
+                                   delta * ev.q_last(self.s2c_level) / sv)
+        self.out_level = self.s2c_level + 1
+        steps = set(self.c2s.steps()) | set(self.s2c.steps())
+        k = s
+        while k < n // 2:
+            steps.add(k)
+            k <<= 1
+        ev.add_rotation_keys(sorted(steps), conj=True)
+
+    def levels_needed(self):
+        return self.out_level
+
+    def eval_mod(self, w):
+        """w in [-1, 1] real slots, w = (m/q0 + I)/Kb  ->  sin(2 pi (m/q0 + I)) ~ 2 pi m / q0"""
+        ev = self.ev
+        c = self.cheb(w, self.delta)
+        for _ in range(self.r):
+            c = ev.square_double_minus_one(c)
+        return c
+
+    def bootstrap(self, ct):
+        ev = self.ev
+        in_scale = ct.scale
+        assert abs(in_scale / self.delta - 1.0) < 0.01, "the bootstrapper was set up for ciphertexts of scale delta"
+        q0 = ev.q[0]
+        t = ev.mod_raise(ev.drop(ct, ev.bottom))
+        t.scale = float(q0)                                   # src/boot/Bootstrapper.cu:2867-2868
+        k = self.s
+        while k < ev.n // 2:                                  # SubSum
+            t = ev.add(t, ev.rotate(t, k))
+            k <<= 1
+        half = self.c2s.apply(t)                              # slots: (x_k + i x_{k+s}) / (2 Kb)
+        cj = ev.conj(half)
+        re = ev.add(half, cj)                                 # x_k / Kb
+        im = ev.neg(ev.mul_i(ev.sub(half, cj)))               # x_{k+s} / Kb
+        re, im = self.eval_mod(re), self.eval_mod(im)
+        v = ev.add(re, ev.mul_i(im))                          # 2 pi (m_k + i m_{k+s}) / q0
+        out = self.s2c.apply(v)                               # slots: message * in_scale / delta
+        out.scale = out.scale * in_scale / self.delta         # src/boot/Bootstrapper.cu:2933 (a ratio of ~1)
+        return out

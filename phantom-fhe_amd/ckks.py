@@ -1,0 +1,321 @@
+"""Scheme-level CKKS evaluator over the C ABI, plus a plaintext-ring simulator with the same interface.
+
+The reference drives its kernels from C++ host classes (`CKKSEvaluator`, include/boot/ckks_evaluator.cuh;
+`Bootstrapper`, src/boot/Bootstrapper.cu).  This module is the corresponding host orchestration for
+this repository: ciphertext objects that carry (level, scale), the evaluator operations the
+bootstrapper needs, and nothing that computes on polynomials itself — every operation of
+`GpuEvaluator` is one or a few C-ABI calls (`phantom_fhe_amd.PhantomContext`).
+
+`SimEvaluator` implements the same interface on *plaintext polynomials* (float64 coefficient
+vectors, negacyclic products by FFT): no encryption, no noise, but the same ring, automorphisms,
+levels, scales and modulus raising, so the algebra and the scale bookkeeping of circuits built on
+the interface (bootstrap.py) can be tested on a CPU without the HIP library.  It is a test double,
+not a fallback: nothing in the GPU path uses it.
+
+Levels are the reference's chain indices: 1 is the top data level (all of Q), each rescale adds one.
+"""
+import numpy as np
+
+
+class Ct:
+    """Ciphertext handle: data (device tensor [2][l][N], or a coefficient vector in the simulator)."""
+    __slots__ = ("data", "level", "scale")
+
+    def __init__(self, data, level, scale):
+        self.data, self.level, self.scale = data, level, float(scale)
+
+
+class Pt:
+    __slots__ = ("data", "level", "scale")
+
+    def __init__(self, data, level, scale):
+        self.data, self.level, self.scale = data, level, float(scale)
+
+
+class EvaluatorBase:
+    """Shared bookkeeping; back ends implement the underscore-free primitives."""
+
+    def __init__(self, log_n, q_primes, sparse_slots):
+        self.log_n, self.n = log_n, 1 << log_n
+        self.q = [int(v) for v in q_primes]
+        self.s = sparse_slots
+        self.bottom = len(self.q)          # chain index of the one-limb level
+
+    def limbs(self, level):
+        return len(self.q) - (level - 1)
+
+    def q_last(self, level):
+        """the prime a rescale at `level` divides by"""
+        return self.q[self.limbs(level) - 1]
+
+    # ---- derived operations -----------------------------------------------------------------
+    def const_pt(self, c, scale, level):
+        # a constant vector is the constant polynomial: two slots are enough
+        return self.encode(np.array([c, c], dtype=np.complex128), scale, level, 2)
+
+    def add_const(self, a, c):
+        return self.add_plain(a, self.const_pt(c, a.scale, a.level))
+
+    def mul_const(self, a, c, const_scale):
+        return self.mul_plain(a, self.const_pt(c, const_scale, a.level))
+
+    def double(self, a):
+        return self.add(a, a)
+
+    def to_level_scale(self, a, level, scale):
+        """Exact (level, scale): one multiplication by the constant 1 encoded at the scale that makes
+        the rescaled product land on `scale`.  Needs a.level < level."""
+        assert a.level < level, (a.level, level)
+        a = self.drop(a, level - 1)
+        return self.rescale(self.mul_const(a, 1.0, scale * self.q_last(level - 1) / a.scale))
+
+    def rotate(self, a, step):
+        return self.rotate_many(a, [step])[0]
+
+    def square_double_minus_one(self, a):
+        """2a^2 - 1 (a Chebyshev doubling / a cosine double angle), one level"""
+        t = self.rescale(self.double(self.mul(a, a)))
+        return self.add_const(t, -1.0)
+
+
+# =================================================================================================
+# GPU back end
+# =================================================================================================
+class GpuEvaluator(EvaluatorBase):
+    """Every primitive is a C-ABI call on `ctx` (phantom_fhe_amd.PhantomContext).  Keys are generated
+    on the GPU from `sk` for the rotations announced with `add_rotation_keys`."""
+
+    def __init__(self, pha, ctx, sk, sparse_slots, seed=1000):
+        super().__init__(ctx.log_n, ctx.moduli[:ctx.size_Q], sparse_slots)
+        self.pha, self.ctx, self.sk = pha, ctx, sk
+        self._seed = seed
+        self.rlk = ctx.gen_relinkey(sk, self._next_seed())
+        self.galois = {}
+        self._mono = {}
+
+    def _next_seed(self):
+        self._seed += 1
+        return self._seed
+
+    def elt(self, step):
+        return self.pha.galois_elt_from_step(self.log_n, step)
+
+    def add_rotation_keys(self, steps, conj=True):
+        elts = {self.elt(s) for s in steps if s % (self.n // 2)}
+        if conj:
+            elts.add(2 * self.n - 1)
+        for e in sorted(elts):
+            if e not in self.galois:
+                self.galois[e] = self.ctx.gen_galois_key(self.sk, e, self._next_seed())
+
+    # ---- encode / encrypt ---------------------------------------------------------------------
+    def encode(self, values, scale, level, sparse_slots=None):
+        s = self.s if sparse_slots is None else sparse_slots
+        return Pt(self.ctx.encode(values, scale, level, s), level, scale)
+
+    def encrypt(self, pt):
+        return Ct(self.ctx.encrypt_symmetric(self.sk, pt.data, pt.level, self._next_seed(), self._next_seed()), pt.level, pt.scale)
+
+    def decrypt_decode(self, a, sparse_slots=None):
+        s = self.s if sparse_slots is None else sparse_slots
+        return self.ctx.decode(self.ctx.ckks_decrypt(self.sk, a.data, a.level), a.scale, s, a.level)
+
+    # ---- arithmetic -------------------------------------------------------------------------
+    def _same(self, a, b):
+        assert a.level == b.level, (a.level, b.level)
+        assert abs(a.scale / b.scale - 1.0) < 1e-9, (a.scale, b.scale)
+
+    def add(self, a, b):
+        self._same(a, b)
+        d = a.data.clone()
+        self.ctx.add_inplace(d, b.data)
+        return Ct(d, a.level, a.scale)
+
+    def sub(self, a, b):
+        self._same(a, b)
+        d = a.data.clone()
+        self.ctx.sub_inplace(d, b.data)
+        return Ct(d, a.level, a.scale)
+
+    def neg(self, a):
+        d = a.data.clone()
+        self.ctx.negate_inplace(d)
+        return Ct(d, a.level, a.scale)
+
+    def add_plain(self, a, p):
+        self._same(a, p)
+        d = a.data.clone()
+        self.ctx.add_plain_inplace(d, p.data)
+        return Ct(d, a.level, a.scale)
+
+    def mul_plain(self, a, p):
+        assert a.level == p.level
+        d = a.data.clone()
+        self.ctx.multiply_plain_inplace(d, p.data)
+        return Ct(d, a.level, a.scale * p.scale)
+
+    def mul(self, a, b):
+        import torch
+        assert a.level == b.level
+        d = torch.cat([a.data, torch.zeros_like(a.data[:1])])
+        self.ctx.multiply_and_relin_inplace(a.level, d, b.data, self.rlk)
+        return Ct(d[:2].contiguous(), a.level, a.scale * b.scale)
+
+    def rescale(self, a):
+        import torch
+        out = torch.empty((2, self.limbs(a.level) - 1, self.n), dtype=torch.int64, device=a.data.device)
+        self.ctx.rescale_to_next(a.level, a.data, 2, out)
+        return Ct(out, a.level + 1, a.scale / self.q_last(a.level))
+
+    def drop(self, a, level):
+        assert level >= a.level
+        d, lv = a.data, a.level
+        while lv < level:
+            d = self.ctx.mod_switch_to_next(lv, d)
+            lv += 1
+        return Ct(d, level, a.scale)
+
+    def rotate_many(self, a, steps):
+        half = self.n // 2
+        live = [s for s in steps if s % half]
+        outs = {}
+        if live:
+            elts = [self.elt(s) for s in live]
+            res = self.ctx.rotate_hoisted(a.level, a.data, elts, [self.galois[e] for e in elts])
+            outs = {s: Ct(r, a.level, a.scale) for s, r in zip(live, res)}
+        return [outs[s] if s % half else a for s in steps]
+
+    def conj(self, a):
+        d = a.data.clone()
+        self.ctx.apply_galois_inplace(a.level, d, 2 * self.n - 1, self.galois[2 * self.n - 1])
+        return Ct(d, a.level, a.scale)
+
+    def mul_i(self, a):
+        """multiplication of every slot by i = multiplication of the polynomial by X^(N/2): exact"""
+        key = a.level
+        if key not in self._mono:
+            l = self.limbs(a.level)
+            h = np.zeros((l, self.n), dtype=np.uint64)
+            h[:, self.n // 2] = 1
+            m = self.pha.to_device(h)
+            self.ctx.nwt_2d_radix8_forward_inplace(m, l, 0)
+            self._mono[key] = m
+        d = a.data.clone()
+        self.ctx.multiply_plain_inplace(d, self._mono[key])
+        return Ct(d, a.level, a.scale)
+
+    def mod_raise(self, a):
+        assert a.level == self.bottom
+        return Ct(self.ctx.mod_raise(a.data), 1, a.scale)
+
+
+# =================================================================================================
+# plaintext-ring simulator (CPU test double)
+# =================================================================================================
+class SimEvaluator(EvaluatorBase):
+    """Plaintext polynomials as float64 coefficient vectors: the ring, the automorphisms, levels and
+    scales of the real thing; no encryption and no noise.  mod_raise adds q0 * I(X) with a random
+    small integer polynomial I, which is what raising the modulus of a real ciphertext does to its
+    decryption (I = (c0 + c1*s - m) / q0 over the integers)."""
+
+    def __init__(self, log_n, q_primes, sparse_slots, hamming_weight=32, seed=0):
+        super().__init__(log_n, q_primes, sparse_slots)
+        self.rng = np.random.default_rng(seed)
+        self.h = hamming_weight
+        self.last_I = None
+
+    def add_rotation_keys(self, steps, conj=True):
+        pass
+
+    # encode / decode by the definition of the embedding (oracle-free: this module ships in the product)
+    @staticmethod
+    def _matrix(s):
+        m = 4 * s
+        rot = [pow(5, j, m) for j in range(s)]
+        e = np.array([[(r * k) % m for k in range(s)] for r in rot], dtype=np.float64)
+        return np.exp(2j * np.pi * e / m)
+
+    def encode(self, values, scale, level, sparse_slots=None):
+        s = self.s if sparse_slots is None else sparse_slots
+        z = np.zeros(s, dtype=np.complex128)
+        z[:len(values)] = values
+        u = self._matrix(s).conj().T @ z / s
+        gap = self.n // (2 * s)
+        c = np.zeros(self.n)
+        c[np.arange(s) * gap] = np.rint(scale * u.real)
+        c[(np.arange(s) + s) * gap] = np.rint(scale * u.imag)
+        return Pt(c, level, scale)
+
+    def encrypt(self, pt):
+        return Ct(pt.data.copy(), pt.level, pt.scale)
+
+    def decrypt_decode(self, a, sparse_slots=None):
+        s = self.s if sparse_slots is None else sparse_slots
+        gap = self.n // (2 * s)
+        u = (a.data[np.arange(s) * gap] + 1j * a.data[(np.arange(s) + s) * gap]) / a.scale
+        return self._matrix(s) @ u
+
+    def _same(self, a, b):
+        assert a.level == b.level, (a.level, b.level)
+        assert abs(a.scale / b.scale - 1.0) < 1e-9, (a.scale, b.scale)
+
+    def add(self, a, b):
+        self._same(a, b)
+        return Ct(a.data + b.data, a.level, a.scale)
+
+    def sub(self, a, b):
+        self._same(a, b)
+        return Ct(a.data - b.data, a.level, a.scale)
+
+    def neg(self, a):
+        return Ct(-a.data, a.level, a.scale)
+
+    def add_plain(self, a, p):
+        self._same(a, p)
+        return Ct(a.data + p.data, a.level, a.scale)
+
+    def _negacyclic(self, x, y):
+        n = self.n
+        f = np.fft.rfft(x, 2 * n) * np.fft.rfft(y, 2 * n)
+        full = np.fft.irfft(f, 2 * n)
+        return full[:n] - full[n:]
+
+    def mul_plain(self, a, p):
+        assert a.level == p.level
+        return Ct(self._negacyclic(a.data, p.data), a.level, a.scale * p.scale)
+
+    def mul(self, a, b):
+        assert a.level == b.level
+        return Ct(self._negacyclic(a.data, b.data), a.level, a.scale * b.scale)
+
+    def rescale(self, a):
+        q = self.q_last(a.level)
+        return Ct(a.data / q, a.level + 1, a.scale / q)
+
+    def drop(self, a, level):
+        assert level >= a.level
+        return Ct(a.data, level, a.scale)
+
+    def _automorphism(self, c, g):
+        n = self.n
+        idx = (np.arange(n) * g) % (2 * n)
+        out = np.zeros(n)
+        sign = np.where(idx >= n, -1.0, 1.0)
+        out[idx % n] = sign * c
+        return out
+
+    def rotate_many(self, a, steps):
+        return [Ct(self._automorphism(a.data, pow(5, st % (self.n // 2), 2 * self.n)), a.level, a.scale) for st in steps]
+
+    def conj(self, a):
+        return Ct(self._automorphism(a.data, 2 * self.n - 1), a.level, a.scale)
+
+    def mul_i(self, a):
+        h = self.n // 2
+        return Ct(np.concatenate([-a.data[h:], a.data[:h]]), a.level, a.scale)
+
+    def mod_raise(self, a):
+        assert a.level == self.bottom
+        sigma = np.sqrt((self.h + 1) / 12.0)
+        self.last_I = np.rint(self.rng.normal(0.0, sigma, self.n))
+        return Ct(a.data + self.q[0] * self.last_I, 1, a.scale)

@@ -116,4 +116,20 @@ __global__ __launch_bounds__(256) void poly_binary_kernel(uint64_t *dst, const u
     *reinterpret_cast<ulonglong2 *>(dst + id) = r;
 }
 
+// Bootstrapper::modraise_inplace (src/boot/Bootstrapper.cu:2801-2861): a coefficient-form residue x
+// modulo q0 is lifted to its centred representative (x - q0 if x > q0/2) and reduced modulo every
+// limb of the top level.  src: [polys][n] (limb 0 in coefficient form), dst: [polys][limbs][n].
+__global__ __launch_bounds__(256) void mod_raise_kernel(uint64_t *dst, const uint64_t *src, const DModulus *mod,
+                                                        uint32_t limbs, uint32_t n) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x, p = blockIdx.y;
+    const uint64_t q0 = mod[0].value, x = src[static_cast<size_t>(p) * n + k];
+    const bool high = x > (q0 >> 1);
+    for (uint32_t l = 0; l < limbs; l++) {
+        const DModulus m = mod[l];
+        uint64_t r = barrett64(x, m.value, m.ratio1);
+        if (high) r = csub(r + m.value - barrett64(q0, m.value, m.ratio1), m.value);
+        dst[(static_cast<size_t>(p) * limbs + l) * n + k] = r;
+    }
+}
+
 }  // namespace pha

@@ -1557,4 +1557,46 @@ int pha_rotate_hoisted(pha_context *ctx, size_t chain_index, const uint64_t *ct,
     return PHA_OK;
 }
 
+// ---- bootstrapping primitives (src/boot/Bootstrapper.cu) ------------------------------------------
+int pha_mod_raise(pha_context *ctx, const uint64_t *src, uint64_t *dst, pha_stream_t stream) {
+    REQUIRE_CTX(src && dst);
+    hipStream_t st = as_stream(stream);
+    const size_t n = ctx->n, limbs = ctx->size_Q;
+    uint64_t *coeff;
+    PHA_TRY(ensure_workspace(ctx, 2 * n, &coeff));
+    // limb 0 of both polys to coefficient form (the lowest level has one limb: polys are n apart)
+    NttRange r0;
+    PHA_TRY(make_range(ctx, 1, 0, 0, 0, 0, 0, r0));
+    PHA_TRY(ntt_backward(ctx, coeff, src, 2, n, r0, EPI_NONE, Epilogue{}, st));
+    hipLaunchKernelGGL(mod_raise_kernel, dim3(static_cast<uint32_t>(n / 256), 2u), dim3(256), 0, st, dst, coeff, ctx->d_mod.p,
+                       static_cast<uint32_t>(limbs), static_cast<uint32_t>(n));
+    PHA_TRY(check_launch("mod_raise"));
+    NttRange r;
+    PHA_TRY(make_range(ctx, limbs, 0, 0, 0, 0, 0, r));
+    return ntt_forward(ctx, dst, 2, limbs * n, r, EPI_NONE, Epilogue{}, st);
+}
+
+// gen_secretkey with secret_key_hamming_weight (src/secretkey.cu:401-433): exactly `hamming_weight`
+// nonzero (+-1) coefficients at positions drawn without replacement from the seeded generator
+int pha_gen_secretkey_sparse(pha_context *ctx, uint64_t seed, size_t hamming_weight, uint64_t *sk, pha_stream_t stream) {
+    REQUIRE_CTX(sk);
+    const size_t n = ctx->n, L = ctx->size_QP;
+    if (hamming_weight == 0 || hamming_weight > n) return fail(PHA_ERR_INVALID_ARGUMENT, "hamming weight out of range");
+    std::vector<uint32_t> pos(n);
+    for (size_t i = 0; i < n; i++) pos[i] = static_cast<uint32_t>(i);
+    std::vector<uint64_t> h(L * n, 0);
+    for (size_t i = 0; i < hamming_weight; i++) {  // partial Fisher-Yates
+        const size_t j = i + static_cast<size_t>(host_rnd_at(seed, 2 * i) % (n - i));
+        std::swap(pos[i], pos[j]);
+        const bool minus = host_rnd_at(seed, 2 * i + 1) & 1;
+        for (size_t l = 0; l < L; l++) h[l * n + pos[i]] = minus ? ctx->moduli[l] - 1 : 1;
+    }
+    hipStream_t st = as_stream(stream);
+    HIP_TRY(hipMemcpyAsync(sk, h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // h goes out of scope
+    NttRange r;
+    PHA_TRY(make_range(ctx, L, 0, 0, 0, 0, 0, r));
+    return ntt_forward(ctx, sk, 1, 0, r, EPI_NONE, Epilogue{}, st);
+}
+
 }  // extern "C"
