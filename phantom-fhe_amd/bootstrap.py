@@ -38,9 +38,9 @@ class LinearTransform:
     """z -> M z on the s sparse slots by baby-step/giant-step diagonals, one level.
     M z = sum_g rot( sum_b rot(diag_{g*n1+b}, -g*n1) * rot(z, b), g*n1 )."""
 
-    def __init__(self, ev, matrix, level, diag_scale):
+    def __init__(self, ev, matrix, level, diag_scale, rescales=1):
         s = matrix.shape[0]
-        self.ev, self.s, self.level, self.diag_scale = ev, s, level, diag_scale
+        self.ev, self.s, self.level, self.diag_scale, self.rescales = ev, s, level, diag_scale, rescales
         self.n1 = 1 << math.ceil(math.log2(s) / 2)
         self.n2 = s // self.n1
         j = np.arange(s)
@@ -74,7 +74,9 @@ class LinearTransform:
             if g:
                 inner = ev.rotate(inner, g * self.n1)
             total = inner if total is None else ev.add(total, inner)
-        return ev.rescale(total)
+        for _ in range(self.rescales):      # 2: diagonals encoded over two primes (double precision)
+            total = ev.rescale(total)
+        return total
 
 
 class ChebyshevEvaluator:
@@ -175,7 +177,7 @@ class ChebyshevEvaluator:
 
 
 class Bootstrapper:
-    """Sparse-slot bootstrapping.  Levels used: 1 (CoeffToSlot) + cheb.depth + r (EvalMod) + 1
+    """Sparse-slot bootstrapping.  Levels used: 2 (CoeffToSlot) + cheb.depth + r (EvalMod) + 1
     (SlotToCoeff), starting from level 1 after the modulus raise.  The primes under the two linear
     transforms should be large (the reference's parameter sets do the same) so that their
     diagonals can be encoded precisely; the EvalMod primes should be close to the working scale."""
@@ -190,13 +192,16 @@ class Bootstrapper:
         self.cheb = ChebyshevEvaluator(ev, np.polynomial.chebyshev.chebinterpolate(f, degree), baby_log)
         A = slot_matrix(s)
         q0 = ev.q[0]
-        # level 1: diagonals at the scale that turns the re-declared scale q0 into delta after the rescale
-        c2s_scale = delta * ev.q_last(1) / q0
-        self.c2s = LinearTransform(ev, A.conj().T / (s * self.g * self.Kb * 2.0), 1, c2s_scale)
-        self.evalmod_level = 2
-        self.s2c_level = 2 + self.cheb.depth + r
+        # levels 1-2: the CoeffToSlot input carries q0*I*g (~2^63), and an error eps in x = m/q0 + I comes
+        # back multiplied by q0/delta in the message, so the diagonals are encoded over TWO primes (their
+        # integers would otherwise have only ~27 bits) at the scale that turns the re-declared scale q0
+        # into delta after both rescales
+        c2s_scale = delta * ev.q_last(1) * ev.q_last(2) / q0
+        self.c2s = LinearTransform(ev, A.conj().T / (s * self.g * self.Kb * 2.0), 1, c2s_scale, rescales=2)
+        self.evalmod_level = 3
+        self.s2c_level = 3 + self.cheb.depth + r
         # scale of the EvalMod output: delta after the polynomial, squared and rescaled by every double angle
-        sv, lvl = delta, 2 + self.cheb.depth
+        sv, lvl = delta, 3 + self.cheb.depth
         for _ in range(r):
             sv, lvl = sv * sv / ev.q_last(lvl), lvl + 1
         # A/(2 pi) undoes the sine's factor, q0/delta brings the message back from units of q0 to the

@@ -8,8 +8,8 @@ import numpy as np
 import pytest
 
 N, LOG_N = 4096, 12
-# q0, two levels left after bootstrapping, SlotToCoeff, 9 EvalMod levels, CoeffToSlot (large prime)
-Q_BITS = [50] + [40] * 2 + [40] + [40] * 9 + [58]
+# q0, two levels left after bootstrapping, SlotToCoeff, 9 EvalMod levels, CoeffToSlot (two primes)
+Q_BITS = [50] + [40] * 2 + [40] + [40] * 9 + [40, 58]
 
 
 def _chain(orc, extra=()):
@@ -42,12 +42,12 @@ def test_bootstrap_on_the_simulator(orc, pha, s):
     q = _chain(orc)
     ev = SimEvaluator(LOG_N, q, s, hamming_weight=32, seed=s)
     bs = Bootstrapper(ev, K=12, r=3, degree=31)
-    assert bs.levels_needed() == 12
+    assert bs.levels_needed() == 13
     rng = np.random.default_rng(1)
     msg = rng.uniform(-1, 1, s) + 1j * rng.uniform(-1, 1, s)
     out = bs.bootstrap(ev.encrypt(ev.encode(msg, 2.0 ** 40, ev.bottom)))
     assert np.abs(ev.last_I).max() >= 3                     # the modulus raise really added multiples of q0
-    assert out.level == 12 and abs(out.scale / 2.0 ** 40 - 1) < 1e-3
+    assert out.level == 13 and abs(out.scale / 2.0 ** 40 - 1) < 1e-3
     # the sine's cubic term: (2 pi |m| / q0)^2 / 6 relative, |m|/q0 = 2^-10
     assert np.abs(ev.decrypt_decode(out) - msg).max() < 3e-5
 
@@ -67,7 +67,7 @@ def test_bootstrap_on_the_gpu(gpu, pha, orc, s):
     ct = ev.encrypt(ev.encode(msg, 2.0 ** 40, ev.bottom))
     assert np.abs(ev.decrypt_decode(ct) - msg).max() < 1e-7
     out = bs.bootstrap(ct)
-    assert out.level == 12 and ev.limbs(out.level) == 3     # two multiplicative levels regained
+    assert out.level == 13 and ev.limbs(out.level) == 3     # two multiplicative levels regained
     got = ev.decrypt_decode(out)
     assert np.abs(got - msg).max() < 1e-3
     # and the refreshed ciphertext computes: square it, rescale, compare slot-wise

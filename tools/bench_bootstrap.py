@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Sparse-slot CKKS bootstrapping latency at N=2^16 on one GPU (BASELINE config 5's primitive;
+the reference's bootstrap_sparse*, src/boot/Bootstrapper.cu).  Prints one JSON line.
+
+    python tools/bench_bootstrap.py [--slots 64] [--log-n 16] [--reps 3]
+"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import phantom_fhe_amd as pha
+from phantom_fhe_amd.bootstrap import Bootstrapper
+from phantom_fhe_amd.ckks import GpuEvaluator
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--slots", type=int, default=64)
+    ap.add_argument("--log-n", type=int, default=16)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--extra-levels", type=int, default=4)
+    ap.add_argument("--alpha", type=int, default=4)
+    args = ap.parse_args()
+    n = 1 << args.log_n
+    q_bits = [50] + [40] * args.extra_levels + [40] + [40] * (9 if args.log_n < 15 else 10) + [40, 58]
+    while len(q_bits) % args.alpha:
+        q_bits.insert(1, 40)
+    mods = pha.coeff_modulus_create(n, q_bits + [60] * args.alpha)
+    ctx = pha.PhantomContext(args.log_n, mods, args.alpha)
+    sk = ctx.gen_secretkey(21, hamming_weight=192 if args.log_n >= 15 else 32)
+    ev = GpuEvaluator(pha, ctx, sk, args.slots)
+    t0 = time.perf_counter()
+    bs = Bootstrapper(ev, K=25 if args.log_n >= 15 else 12, r=3 if args.log_n < 15 else 4, degree=31)
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t0
+    rng = np.random.default_rng(2)
+    msg = rng.uniform(-1, 1, args.slots) + 1j * rng.uniform(-1, 1, args.slots)
+    ct = ev.encrypt(ev.encode(msg, 2.0 ** 40, ev.bottom))
+    out = bs.bootstrap(ct)
+    err = float(np.abs(ev.decrypt_decode(out) - msg).max())
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(args.reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = bs.bootstrap(ct)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    print(json.dumps({"metric": "sparse-slot CKKS bootstrap ms", "value": 1e3 * min(times), "unit": "ms", "log_n": args.log_n,
+                      "slots": args.slots, "q_limbs": len(q_bits), "special_primes": args.alpha, "levels_after": ev.limbs(out.level) - 1,
+                      "max_abs_error": err, "setup_s": setup_s, "rotation_keys": len(ev.galois), "n_gpus": 1}), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
