@@ -40,6 +40,7 @@ class EvaluatorBase:
         self.q = [int(v) for v in q_primes]
         self.s = sparse_slots
         self.bottom = len(self.q)          # chain index of the one-limb level
+        self._consts = {}
 
     def limbs(self, level):
         return len(self.q) - (level - 1)
@@ -50,8 +51,13 @@ class EvaluatorBase:
 
     # ---- derived operations -----------------------------------------------------------------
     def const_pt(self, c, scale, level):
-        # a constant vector is the constant polynomial: two slots are enough
-        return self.encode(np.array([c, c], dtype=np.complex128), scale, level, 2)
+        # a constant vector is the constant polynomial: two slots are enough.  Cached: a circuit asks for
+        # the same constants on every run, and an encode synchronises the stream.
+        key = (complex(c), float(scale), level)
+        pt = self._consts.get(key)
+        if pt is None:
+            pt = self._consts[key] = self.encode(np.array([c, c], dtype=np.complex128), scale, level, 2)
+        return pt
 
     def add_const(self, a, c):
         return self.add_plain(a, self.const_pt(c, a.scale, a.level))
@@ -125,21 +131,27 @@ class GpuEvaluator(EvaluatorBase):
         assert a.level == b.level, (a.level, b.level)
         assert abs(a.scale / b.scale - 1.0) < 1e-9, (a.scale, b.scale)
 
+    def _binary(self, fn, a_data, b_data, polys, b_polys):
+        import torch
+        d = torch.empty_like(a_data)
+        rc = fn(self.ctx._h, d.data_ptr(), a_data.data_ptr(), b_data.data_ptr(), a_data.shape[-2], polys, b_polys,
+                self.pha._stream())
+        self.pha._check(rc)
+        return d
+
     def add(self, a, b):
         self._same(a, b)
-        d = a.data.clone()
-        self.ctx.add_inplace(d, b.data)
-        return Ct(d, a.level, a.scale)
+        return Ct(self._binary(self.pha.lib().pha_add_rns_poly, a.data, b.data, 2, 2), a.level, a.scale)
 
     def sub(self, a, b):
         self._same(a, b)
-        d = a.data.clone()
-        self.ctx.sub_inplace(d, b.data)
-        return Ct(d, a.level, a.scale)
+        return Ct(self._binary(self.pha.lib().pha_sub_rns_poly, a.data, b.data, 2, 2), a.level, a.scale)
 
     def neg(self, a):
-        d = a.data.clone()
-        self.ctx.negate_inplace(d)
+        import torch
+        d = torch.empty_like(a.data)
+        self.pha._check(self.pha.lib().pha_negate_rns_poly(self.ctx._h, d.data_ptr(), a.data.data_ptr(), a.data.shape[-2], 2,
+                                                           self.pha._stream()))
         return Ct(d, a.level, a.scale)
 
     def add_plain(self, a, p):
@@ -150,16 +162,15 @@ class GpuEvaluator(EvaluatorBase):
 
     def mul_plain(self, a, p):
         assert a.level == p.level
-        d = a.data.clone()
-        self.ctx.multiply_plain_inplace(d, p.data)
-        return Ct(d, a.level, a.scale * p.scale)
+        return Ct(self._binary(self.pha.lib().pha_multiply_rns_poly, a.data, p.data, 2, 1), a.level, a.scale * p.scale)
 
     def mul(self, a, b):
         import torch
         assert a.level == b.level
-        d = torch.cat([a.data, torch.zeros_like(a.data[:1])])
+        d = torch.empty((3,) + tuple(a.data.shape[1:]), dtype=a.data.dtype, device=a.data.device)
+        d[:2].copy_(a.data)                    # the tensor product writes all three polys
         self.ctx.multiply_and_relin_inplace(a.level, d, b.data, self.rlk)
-        return Ct(d[:2].contiguous(), a.level, a.scale * b.scale)
+        return Ct(d[:2], a.level, a.scale * b.scale)
 
     def rescale(self, a):
         import torch
@@ -169,11 +180,10 @@ class GpuEvaluator(EvaluatorBase):
 
     def drop(self, a, level):
         assert level >= a.level
-        d, lv = a.data, a.level
-        while lv < level:
-            d = self.ctx.mod_switch_to_next(lv, d)
-            lv += 1
-        return Ct(d, level, a.scale)
+        if level == a.level:
+            return a
+        # CKKS mod_switch_to_next only drops limbs (src/evaluate.cu:618-700): one strided copy for all levels
+        return Ct(a.data[:, :self.limbs(level)].contiguous(), level, a.scale)
 
     def rotate_many(self, a, steps):
         half = self.n // 2
