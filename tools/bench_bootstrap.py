@@ -19,22 +19,24 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--extra-levels", type=int, default=4)
     ap.add_argument("--alpha", type=int, default=4)
+    ap.add_argument("--delta-bits", type=int, default=50, help="working scale; q0 has 10 bits more")
     args = ap.parse_args()
     n = 1 << args.log_n
-    q_bits = [50] + [40] * args.extra_levels + [40] + [40] * (9 if args.log_n < 15 else 10) + [40, 58]
+    d = args.delta_bits
+    q_bits = [d + 10] + [d] * args.extra_levels + [d] + [d] * (9 if args.log_n < 15 else 10) + [d, min(60, d + 18)]
     while len(q_bits) % args.alpha:
-        q_bits.insert(1, 40)
+        q_bits.insert(1, d)
     mods = pha.coeff_modulus_create(n, q_bits + [60] * args.alpha)
     ctx = pha.PhantomContext(args.log_n, mods, args.alpha)
     sk = ctx.gen_secretkey(21, hamming_weight=192 if args.log_n >= 15 else 32)
     ev = GpuEvaluator(pha, ctx, sk, args.slots)
     t0 = time.perf_counter()
-    bs = Bootstrapper(ev, K=25 if args.log_n >= 15 else 12, r=3 if args.log_n < 15 else 4, degree=31)
+    bs = Bootstrapper(ev, K=25 if args.log_n >= 15 else 12, r=3 if args.log_n < 15 else 4, degree=31, delta=2.0 ** d)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     rng = np.random.default_rng(2)
     msg = rng.uniform(-1, 1, args.slots) + 1j * rng.uniform(-1, 1, args.slots)
-    ct = ev.encrypt(ev.encode(msg, 2.0 ** 40, ev.bottom))
+    ct = ev.encrypt(ev.encode(msg, 2.0 ** d, ev.bottom))
     out = bs.bootstrap(ct)
     err = float(np.abs(ev.decrypt_decode(out) - msg).max())
     torch.cuda.synchronize()
@@ -46,7 +48,7 @@ def main():
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     print(json.dumps({"metric": "sparse-slot CKKS bootstrap ms", "value": 1e3 * min(times), "unit": "ms", "log_n": args.log_n,
-                      "slots": args.slots, "q_limbs": len(q_bits), "special_primes": args.alpha, "levels_after": ev.limbs(out.level) - 1,
+                      "slots": args.slots, "delta_bits": d, "q_limbs": len(q_bits), "special_primes": args.alpha, "levels_after": ev.limbs(out.level) - 1,
                       "max_abs_error": err, "setup_s": setup_s, "rotation_keys": len(ev.galois), "n_gpus": 1}), flush=True)
     ctx.close()
 
