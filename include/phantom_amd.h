@@ -248,6 +248,10 @@ int pha_sub_rns_poly(pha_context *ctx, uint64_t *dst, const uint64_t *a, const u
                      size_t polys, size_t b_polys, pha_stream_t stream);
 int pha_multiply_rns_poly(pha_context *ctx, uint64_t *dst, const uint64_t *a, const uint64_t *b, size_t coeff_mod_size,
                           size_t polys, size_t b_polys, pha_stream_t stream);
+/* dst = c + a * b (multiply_and_add_rns_poly, src/polymath.cu:230-260): the accumulation step of the
+ * bootstrapper's linear transforms; c has the shape of a, dst may alias c */
+int pha_multiply_add_rns_poly(pha_context *ctx, uint64_t *dst, const uint64_t *a, const uint64_t *b, const uint64_t *c,
+                              size_t coeff_mod_size, size_t polys, size_t b_polys, pha_stream_t stream);
 int pha_negate_rns_poly(pha_context *ctx, uint64_t *dst, const uint64_t *a, size_t coeff_mod_size, size_t polys,
                         pha_stream_t stream);
 /* mod_switch_drop_to_next (src/evaluate.cu:618-700): dst[cipher_size][l-1][N] = src without its

@@ -84,6 +84,7 @@ SIGNATURES = {
     "pha_add_rns_poly": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _vp]),
     "pha_sub_rns_poly": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _vp]),
     "pha_multiply_rns_poly": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _vp]),
+    "pha_multiply_add_rns_poly": (_int, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _vp]),
     "pha_negate_rns_poly": (_int, [_vp, _vp, _vp, _sz, _sz, _vp]),
     "pha_mod_switch_drop_to_next": (_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "pha_ckks_encode": (_int, [_vp, _vp, _sz, _sz, _sz, ctypes.c_double, _vp, _vp]),

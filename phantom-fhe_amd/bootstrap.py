@@ -39,7 +39,7 @@ class LinearTransform:
     M z = sum_g rot( sum_b rot(diag_{g*n1+b}, -g*n1) * rot(z, b), g*n1 )."""
 
     def __init__(self, ev, matrix, level, diag_scale, rescales=1):
-        s = matrix.shape[0]
+        s = matrix.shape[0]                 # the transform's slot count (a power of two <= N/2)
         self.ev, self.s, self.level, self.diag_scale, self.rescales = ev, s, level, diag_scale, rescales
         self.n1 = 1 << math.ceil(math.log2(s) / 2)
         self.n2 = s // self.n1
@@ -51,7 +51,7 @@ class LinearTransform:
                 diag = matrix[j, (j + d) % s]
                 if np.abs(diag).max() < 1e-300:
                     continue
-                self.diags[(g, b)] = ev.encode(np.roll(diag, g * self.n1), diag_scale, level)
+                self.diags[(g, b)] = ev.encode(np.roll(diag, g * self.n1), diag_scale, level, s)
 
     def steps(self):
         return [b for b in range(1, self.n1)] + [g * self.n1 for g in range(1, self.n2)]
@@ -67,8 +67,7 @@ class LinearTransform:
                 pt = self.diags.get((g, b))
                 if pt is None:
                     continue
-                term = ev.mul_plain(babies[b], pt)
-                inner = term if inner is None else ev.add(inner, term)
+                inner = ev.mul_plain_add(inner, babies[b], pt)
             if inner is None:
                 continue
             if g:
@@ -178,39 +177,60 @@ class ChebyshevEvaluator:
 
 class Bootstrapper:
     """Sparse-slot bootstrapping.  Levels used: 2 (CoeffToSlot) + cheb.depth + r (EvalMod) + 1
-    (SlotToCoeff), starting from level 1 after the modulus raise.  The primes under the two linear
-    transforms should be large (the reference's parameter sets do the same) so that their
-    diagonals can be encoded precisely; the EvalMod primes should be close to the working scale."""
+    (SlotToCoeff), starting from level 1 after the modulus raise.  The EvalMod primes should be close
+    to the working scale delta, q0 about 2^10 * delta (the sine is used where it is linear).
 
-    def __init__(self, ev, K=12, r=3, degree=31, delta=2.0 ** 40, baby_log=2):
+    packed (default whenever 2s <= N/2, like the reference's sparse mode): the linear transforms act
+    on the 2s-slot subring, CoeffToSlot leaves the s real parts in slots [0, s) and the s imaginary
+    parts in slots [s, 2s) of ONE ciphertext, so EvalMod runs once.  Otherwise real and imaginary
+    parts go through EvalMod as two ciphertexts."""
+
+    def __init__(self, ev, K=12, r=3, degree=31, delta=2.0 ** 40, baby_log=2, packed=None):
         self.ev, self.K, self.r, self.delta = ev, K, r, delta
         s, n = ev.s, ev.n
-        self.s, self.g = s, n // (2 * s)
+        self.s = s
+        # packing doubles the dimension of the dense linear transforms: it pays while they are small
+        self.packed = (4 * s <= n and s <= 64) if packed is None else packed
+        assert not self.packed or 4 * s <= n
+        S = 2 * s if self.packed else s      # slots of the subring the circuit works in
+        self.S, self.g = S, n // (2 * S)
         self.Kb = K + 0.5
         # Chebyshev interpolant of f(w) = cos(2 pi (Kb w - 1/4) / 2^r) on [-1, 1]
         f = lambda w: np.cos(2.0 * np.pi * (self.Kb * w - 0.25) / (1 << r))  # noqa: E731
         self.cheb = ChebyshevEvaluator(ev, np.polynomial.chebyshev.chebinterpolate(f, degree), baby_log)
         A = slot_matrix(s)
         q0 = ev.q[0]
+        norm = 1.0 / (self.g * self.Kb * 2.0)
+        if self.packed:
+            # u' = U z' are the 2s complex coefficient pairs of the 2s-slot subring; the message sits on the
+            # even ones: Re u'_{2k} = coefficient k, Im u'_{2k} = coefficient k+s.  v = (u'_{2k}/2, -i u'_{2k}/2)
+            # makes v + conj(v) the packed real vector; the odd ones (pure q0*I garbage) are never read.
+            U = slot_matrix(S).conj().T / S
+            c2s_m = np.concatenate([U[0::2], -1j * U[0::2]]) * norm
+            # slots of the output (period s): A (y_first + i y_second)
+            s2c_m = np.tile(np.concatenate([A, 1j * A], axis=1), (2, 1))
+        else:
+            c2s_m = A.conj().T / s * norm
+            s2c_m = A
         # levels 1-2: the CoeffToSlot input carries q0*I*g (~2^63), and an error eps in x = m/q0 + I comes
         # back multiplied by q0/delta in the message, so the diagonals are encoded over TWO primes (their
         # integers would otherwise have only ~27 bits) at the scale that turns the re-declared scale q0
         # into delta after both rescales
         c2s_scale = delta * ev.q_last(1) * ev.q_last(2) / q0
-        self.c2s = LinearTransform(ev, A.conj().T / (s * self.g * self.Kb * 2.0), 1, c2s_scale, rescales=2)
+        self.c2s = LinearTransform(ev, c2s_m, 1, c2s_scale, rescales=2)
         self.evalmod_level = 3
         self.s2c_level = 3 + self.cheb.depth + r
         # scale of the EvalMod output: delta after the polynomial, squared and rescaled by every double angle
         sv, lvl = delta, 3 + self.cheb.depth
         for _ in range(r):
             sv, lvl = sv * sv / ev.q_last(lvl), lvl + 1
-        # A/(2 pi) undoes the sine's factor, q0/delta brings the message back from units of q0 to the
+        # 1/(2 pi) undoes the sine's factor, q0/delta brings the message back from units of q0 to the
         # working scale: the output is a ciphertext of scale delta again
-        self.s2c = LinearTransform(ev, A * (q0 / delta) / (2.0 * np.pi), self.s2c_level,
+        self.s2c = LinearTransform(ev, s2c_m * (q0 / delta) / (2.0 * np.pi), self.s2c_level,
                                    delta * ev.q_last(self.s2c_level) / sv)
         self.out_level = self.s2c_level + 1
         steps = set(self.c2s.steps()) | set(self.s2c.steps())
-        k = s
+        k = S
         while k < n // 2:
             steps.add(k)
             k <<= 1
@@ -234,16 +254,18 @@ class Bootstrapper:
         q0 = ev.q[0]
         t = ev.mod_raise(ev.drop(ct, ev.bottom))
         t.scale = float(q0)                                   # src/boot/Bootstrapper.cu:2867-2868
-        k = self.s
-        while k < ev.n // 2:                                  # SubSum
+        k = self.S
+        while k < ev.n // 2:                                  # SubSum onto the S-slot subring
             t = ev.add(t, ev.rotate(t, k))
             k <<= 1
-        half = self.c2s.apply(t)                              # slots: (x_k + i x_{k+s}) / (2 Kb)
+        half = self.c2s.apply(t)
         cj = ev.conj(half)
-        re = ev.add(half, cj)                                 # x_k / Kb
-        im = ev.neg(ev.mul_i(ev.sub(half, cj)))               # x_{k+s} / Kb
-        re, im = self.eval_mod(re), self.eval_mod(im)
-        v = ev.add(re, ev.mul_i(im))                          # 2 pi (m_k + i m_{k+s}) / q0
+        if self.packed:
+            v = self.eval_mod(ev.add(half, cj))               # slots [0,s): x_k / Kb, [s,2s): x_{k+s} / Kb
+        else:                                                 # half: (x_k + i x_{k+s}) / (2 Kb)
+            re = ev.add(half, cj)
+            im = ev.neg(ev.mul_i(ev.sub(half, cj)))
+            v = ev.add(self.eval_mod(re), ev.mul_i(self.eval_mod(im)))   # 2 pi (m_k + i m_{k+s}) / q0
         out = self.s2c.apply(v)                               # slots: message * in_scale / delta
         out.scale = out.scale * in_scale / self.delta         # src/boot/Bootstrapper.cu:2933 (a ratio of ~1)
         return out

@@ -68,6 +68,11 @@ class EvaluatorBase:
     def double(self, a):
         return self.add(a, a)
 
+    def mul_plain_add(self, acc, a, p):
+        """acc + a * p (back ends may fuse it)"""
+        t = self.mul_plain(a, p)
+        return t if acc is None else self.add(acc, t)
+
     def to_level_scale(self, a, level, scale):
         """Exact (level, scale): one multiplication by the constant 1 encoded at the scale that makes
         the rescaled product land on `scale`.  Needs a.level < level."""
@@ -163,6 +168,17 @@ class GpuEvaluator(EvaluatorBase):
     def mul_plain(self, a, p):
         assert a.level == p.level
         return Ct(self._binary(self.pha.lib().pha_multiply_rns_poly, a.data, p.data, 2, 1), a.level, a.scale * p.scale)
+
+    def mul_plain_add(self, acc, a, p):
+        """acc + a * p in one pass (acc may be None); scales must agree"""
+        if acc is None:
+            return self.mul_plain(a, p)
+        import torch
+        assert a.level == p.level == acc.level and abs(acc.scale / (a.scale * p.scale) - 1.0) < 1e-9
+        d = torch.empty_like(a.data)
+        self.pha._check(self.pha.lib().pha_multiply_add_rns_poly(self.ctx._h, d.data_ptr(), a.data.data_ptr(), p.data.data_ptr(),
+                                                                 acc.data.data_ptr(), a.data.shape[-2], 2, 1, self.pha._stream()))
+        return Ct(d, a.level, acc.scale)
 
     def mul(self, a, b):
         import torch

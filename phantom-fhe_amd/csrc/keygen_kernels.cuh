@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void elementwise_kernel(uint64_t *dst, const u
     *reinterpret_cast<ulonglong2 *>(dst + id) = r;
 }
 
-enum : int { PB_ADD = 0, PB_SUB = 1, PB_MUL = 2, PB_NEG = 3 };
+enum : int { PB_ADD = 0, PB_SUB = 1, PB_MUL = 2, PB_NEG = 3, PB_MAC = 4 };  // MAC: dst = c + a * b
 
 // Ciphertext / plaintext element-wise evaluator arithmetic (src/polymath.cu add_rns_poly,
 // sub_rns_poly, multiply_rns_poly, negate_rns_poly as used by src/evaluate.cu:20-105,442-560):
@@ -91,7 +91,7 @@ enum : int { PB_ADD = 0, PB_SUB = 1, PB_MUL = 2, PB_NEG = 3 };
 template <int OP>
 __global__ __launch_bounds__(256) void poly_binary_kernel(uint64_t *dst, const uint64_t *a, const uint64_t *b,
                                                           const DModulus *mod, uint32_t limbs, uint32_t n,
-                                                          uint32_t b_broadcast) {
+                                                          uint32_t b_broadcast, const uint64_t *c = nullptr) {
     const uint32_t per_limb = n / 512;
     const uint32_t row = blockIdx.x / per_limb, l = row % limbs;
     const uint32_t k = ((blockIdx.x % per_limb) * 256 + threadIdx.x) * 2;
@@ -109,6 +109,10 @@ __global__ __launch_bounds__(256) void poly_binary_kernel(uint64_t *dst, const u
     } else if (OP == PB_MUL) {
         r.x = mul_barrett(x.x, y.x, m);
         r.y = mul_barrett(x.y, y.y, m);
+    } else if (OP == PB_MAC) {
+        const ulonglong2 z = *reinterpret_cast<const ulonglong2 *>(c + id);
+        r.x = csub(mul_barrett(x.x, y.x, m) + z.x, m.value);
+        r.y = csub(mul_barrett(x.y, y.y, m) + z.y, m.value);
     } else {
         r.x = x.x ? m.value - x.x : 0;
         r.y = x.y ? m.value - x.y : 0;

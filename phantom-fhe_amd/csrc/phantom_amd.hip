@@ -1405,14 +1405,14 @@ int pha_gen_galois_key(pha_context *ctx, const uint64_t *sk, uint32_t galois_elt
 // ---- element-wise evaluator arithmetic (src/evaluate.cu:20-105,442-560,618-700) ----------------
 namespace {
 int poly_binary(pha_context *ctx, int op, uint64_t *dst, const uint64_t *a, const uint64_t *b, size_t coeff_mod_size,
-                size_t polys, size_t b_polys, hipStream_t st) {
+                size_t polys, size_t b_polys, hipStream_t st, const uint64_t *c = nullptr) {
     if (coeff_mod_size == 0 || coeff_mod_size > ctx->size_QP || polys == 0 || (op != PB_NEG && b_polys != polys && b_polys != 1))
         return fail(PHA_ERR_INVALID_ARGUMENT, "poly number mismatch");
     const uint32_t n = static_cast<uint32_t>(ctx->n), limbs = static_cast<uint32_t>(coeff_mod_size);
     const dim3 grid(static_cast<uint32_t>(polys) * limbs * (n / 512));
     const uint32_t bc = (b_polys == 1 && polys > 1) ? 1u : 0u;
-#define PB_CASE(OP) case OP: hipLaunchKernelGGL((poly_binary_kernel<OP>), grid, dim3(256), 0, st, dst, a, b, ctx->d_mod.p, limbs, n, bc); break;
-    switch (op) { PB_CASE(PB_ADD) PB_CASE(PB_SUB) PB_CASE(PB_MUL) PB_CASE(PB_NEG) }
+#define PB_CASE(OP) case OP: hipLaunchKernelGGL((poly_binary_kernel<OP>), grid, dim3(256), 0, st, dst, a, b, ctx->d_mod.p, limbs, n, bc, c); break;
+    switch (op) { PB_CASE(PB_ADD) PB_CASE(PB_SUB) PB_CASE(PB_MUL) PB_CASE(PB_NEG) PB_CASE(PB_MAC) }
 #undef PB_CASE
     return check_launch("poly_binary");
 }
@@ -1432,6 +1432,11 @@ int pha_multiply_rns_poly(pha_context *ctx, uint64_t *dst, const uint64_t *a, co
                           size_t polys, size_t b_polys, pha_stream_t stream) {
     REQUIRE_CTX(dst && a && b);
     return poly_binary(ctx, PB_MUL, dst, a, b, coeff_mod_size, polys, b_polys, as_stream(stream));
+}
+int pha_multiply_add_rns_poly(pha_context *ctx, uint64_t *dst, const uint64_t *a, const uint64_t *b, const uint64_t *c,
+                              size_t coeff_mod_size, size_t polys, size_t b_polys, pha_stream_t stream) {
+    REQUIRE_CTX(dst && a && b && c);
+    return poly_binary(ctx, PB_MAC, dst, a, b, coeff_mod_size, polys, b_polys, as_stream(stream), c);
 }
 int pha_negate_rns_poly(pha_context *ctx, uint64_t *dst, const uint64_t *a, size_t coeff_mod_size, size_t polys,
                         pha_stream_t stream) {

@@ -35,14 +35,14 @@ def test_chebyshev_and_linear_transform_on_the_simulator(orc, pha):
     assert np.abs(ev.decrypt_decode(lt.apply(ev.encrypt(ev.encode(z, 2.0 ** 40, 3)))) - M @ z).max() < 1e-9
 
 
-@pytest.mark.parametrize("s", [4, 16, 64])
-def test_bootstrap_on_the_simulator(orc, pha, s):
+@pytest.mark.parametrize("s,packed", [(4, True), (16, True), (64, True), (16, False)])
+def test_bootstrap_on_the_simulator(orc, pha, s, packed):
     from phantom_fhe_amd.bootstrap import Bootstrapper
     from phantom_fhe_amd.ckks import SimEvaluator
     q = _chain(orc)
     ev = SimEvaluator(LOG_N, q, s, hamming_weight=32, seed=s)
-    bs = Bootstrapper(ev, K=12, r=3, degree=31)
-    assert bs.levels_needed() == 13
+    bs = Bootstrapper(ev, K=12, r=3, degree=31, packed=packed)
+    assert bs.levels_needed() == 13 and bs.packed == packed
     rng = np.random.default_rng(1)
     msg = rng.uniform(-1, 1, s) + 1j * rng.uniform(-1, 1, s)
     out = bs.bootstrap(ev.encrypt(ev.encode(msg, 2.0 ** 40, ev.bottom)))
@@ -53,15 +53,15 @@ def test_bootstrap_on_the_simulator(orc, pha, s):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("s", [8, 32])
-def test_bootstrap_on_the_gpu(gpu, pha, orc, s):
+@pytest.mark.parametrize("s,packed", [(8, True), (32, True), (16, False)])
+def test_bootstrap_on_the_gpu(gpu, pha, orc, s, packed):
     from phantom_fhe_amd.bootstrap import Bootstrapper
     from phantom_fhe_amd.ckks import GpuEvaluator
     mods = orc.coeff_modulus_create(N, Q_BITS + [60])
     ctx = pha.PhantomContext(LOG_N, mods, 1)
     sk = ctx.gen_secretkey(21, hamming_weight=32)
     ev = GpuEvaluator(pha, ctx, sk, s)
-    bs = Bootstrapper(ev, K=12, r=3, degree=31)
+    bs = Bootstrapper(ev, K=12, r=3, degree=31, packed=packed)
     rng = np.random.default_rng(2)
     msg = rng.uniform(-1, 1, s) + 1j * rng.uniform(-1, 1, s)
     ct = ev.encrypt(ev.encode(msg, 2.0 ** 40, ev.bottom))
