@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the HMult/rotate/bootstrap side measurements")
     ap.add_argument("--pmc-traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="per-launch HBM bytes of the dominant kernel from a separate rocprofv3 --pmc pass")
     return ap.parse_args()
@@ -132,6 +133,61 @@ def cpu_baseline(mods, budget_s=12.0):
                       f"OpenMP over limbs"}
 
 
+def secondary_metrics(torch, pha):
+    """HMult+relin / rotate / rescale at config-3 shapes (N=2^16, 36 + 12 limbs, dnum 3) and one sparse-slot
+    bootstrap (N=2^16, 64 slots), single GPU, event-timed."""
+    import numpy as np
+    res = {}
+    size_q, size_p = 36, 12
+    mods = pha.coeff_modulus_create(N, [60] + [50] * (size_q - 1) + [60] * size_p)
+    ctx = pha.PhantomContext(LOG_N, mods, size_p)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    lo = int(mods.min())
+    rnd = lambda *shape: torch.randint(0, lo, (*shape, N), dtype=torch.int64, device="cuda", generator=g)  # noqa: E731
+    evk = pha.EvalKey([rnd(2, size_q + size_p) for _ in range(size_q // size_p)])
+    ct1, ct2 = rnd(3, size_q), rnd(2, size_q)
+    dst = torch.empty((2, size_q - 1, N), dtype=torch.int64, device="cuda")
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        return event_time_ms(torch, fn, reps)
+
+    res["hmult_relin_ms"] = timed(lambda: ctx.multiply_and_relin_inplace(1, ct1, ct2, evk))
+    res["rotate_ms"] = timed(lambda: ctx.apply_galois_inplace(1, ct2, 5, evk))
+    res["rescale_ms"] = timed(lambda: ctx.rescale_to_next(1, ct2, 2, dst))
+    res["config"] = "N=2^16, 36 Q limbs + 12 special primes (dnum 3), uniform synthetic ciphertexts and keys"
+    ctx.close()
+    del evk, ct1, ct2, dst
+
+    from phantom_fhe_amd.bootstrap import Bootstrapper
+    from phantom_fhe_amd.ckks import GpuEvaluator
+    d, alpha, slots = 50, 4, 64
+    q_bits = [d + 10] + [d] * 4 + [d] + [d] * 10 + [d, 60]
+    while len(q_bits) % alpha:
+        q_bits.insert(1, d)
+    mods = pha.coeff_modulus_create(N, q_bits + [60] * alpha)
+    ctx = pha.PhantomContext(LOG_N, mods, alpha)
+    ev = GpuEvaluator(pha, ctx, ctx.gen_secretkey(21, hamming_weight=192), slots)
+    bs = Bootstrapper(ev, K=25, r=4, degree=31, delta=2.0 ** d)
+    msg = np.random.default_rng(2).uniform(-1, 1, slots) + 1j * np.random.default_rng(3).uniform(-1, 1, slots)
+    ct = ev.encrypt(ev.encode(msg, 2.0 ** d, ev.bottom))
+    out = bs.bootstrap(ct)
+    res["bootstrap_max_abs_error"] = float(np.abs(ev.decrypt_decode(out) - msg).max())
+    times = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bs.bootstrap(ct)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    res["bootstrap_ms"] = 1e3 * min(times)
+    res["bootstrap_config"] = f"N=2^16, {slots} sparse slots, {len(q_bits)} Q limbs + {alpha} special primes, h=192, scale 2^{d}"
+    ctx.close()
+    return res
+
+
 def main():
     args = parse()
     import numpy as np
@@ -215,6 +271,15 @@ def main():
             "transform_frac": algo / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "forward_transform_ms": fwd_ms,
             "phases": phase,
         }
+        if not args.no_secondary and world == 1:
+            # the other headline numbers of BASELINE.json (HMult+relin, rotate, bootstrap) on this GPU; they do
+            # not enter `value`
+            try:
+                ctx.close()
+                out["secondary"] = secondary_metrics(torch, pha)
+                ctx = pha.PhantomContext(LOG_N, mods, 0)
+            except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline
+                out["secondary"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(mods)
         print(json.dumps(out), flush=True)
