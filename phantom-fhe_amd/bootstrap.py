@@ -78,6 +78,114 @@ class LinearTransform:
         return total
 
 
+# ---- linear maps as sparse sets of generalised diagonals ---------------------------------------------
+# {d: v} stands for x -> sum_d v * rot(x, d) with rot(x, d)[j] = x[(j + d) mod S].
+def compose_diagonals(outer, inner, S):
+    """(outer o inner): v1 * rot(v2 * rot(x, d2), d1) = v1 * rot(v2, d1) * rot(x, d1 + d2)"""
+    out = {}
+    for d1, v1 in outer.items():
+        for d2, v2 in inner.items():
+            d = (d1 + d2) % S
+            term = v1 * np.roll(v2, -d1)
+            out[d] = out[d] + term if d in out else term
+    return {d: v for d, v in out.items() if np.abs(v).max() > 1e-300}
+
+
+def special_fft_stage(S, length, inverse):
+    """One radix-2 stage of the special FFT over the rotation group (the butterflies of src/fft.cu with
+    twiddle exp(2 pi i (5^j mod 4 len) / (4 len))) as three diagonals.  Forward: (u, v) -> (u + w v, u - w v);
+    inverse: (a, b) -> ((a + b)/2, (a - b) conj(w) / 2).  slot_matrix(S) = F_S o ... o F_4 o F_2 o bitrev."""
+    lenh, lenq = length // 2, length * 4
+    j = np.arange(S) % length
+    first = j < lenh
+    tw = np.exp(2j * np.pi * np.array([pow(5, int(t % lenh), lenq) for t in j]) / lenq)
+    if not inverse:
+        parts = [(0, np.where(first, 1.0, -tw)), (lenh, np.where(first, tw, 0.0)), (S - lenh, np.where(first, 0.0, 1.0))]
+    else:
+        parts = [(0, np.where(first, 0.5, -0.5 * np.conj(tw))), (lenh, np.where(first, 0.5, 0.0)),
+                 (S - lenh, np.where(first, 0.0, 0.5 * np.conj(tw)))]
+    out = {}
+    for d, v in parts:      # at length == S the offsets lenh and S - lenh coincide
+        d %= S
+        v = v.astype(np.complex128)
+        out[d] = out[d] + v if d in out else v
+    return out
+
+
+def special_fft_groups(S, n_groups, inverse):
+    """The log2(S) stages merged into n_groups maps, in application order.  Forward order is
+    len = 2, 4, .., S on bit-reversed input; the inverse applies len = S, .., 2 and leaves its output
+    bit-reversed — the two permutations cancel around the slot-wise EvalMod."""
+    lengths = [1 << k for k in range(1, S.bit_length())]
+    if inverse:
+        lengths = lengths[::-1]
+    per = [len(lengths) // n_groups + (1 if i < len(lengths) % n_groups else 0) for i in range(n_groups)]
+    groups, pos = [], 0
+    for cnt in per:
+        m = {0: np.ones(S, dtype=np.complex128)}
+        for ln in lengths[pos:pos + cnt]:
+            m = compose_diagonals(special_fft_stage(S, ln, inverse), m, S)
+        groups.append(m)
+        pos += cnt
+    return [g for g in groups if g]
+
+
+def dense_to_diagonals(matrix):
+    S = matrix.shape[0]
+    j = np.arange(S)
+    out = {}
+    for d in range(S):
+        v = matrix[j, (j + d) % S]
+        if np.abs(v).max() > 1e-300:
+            out[d] = v
+    return out
+
+
+class DiagonalTransform:
+    """x -> sum_d v_d * rot(x, d) on S slots with baby-step/giant-step rotations over the offsets that
+    occur (offsets are multiples of a stride: d = stride * (g * n1 + b)); the baby rotations of the input
+    share one modup.  `rescales` levels are consumed (2: diagonals encoded over two primes)."""
+
+    def __init__(self, ev, diagonals, S, level, diag_scale, rescales=1):
+        self.ev, self.S, self.level, self.rescales = ev, S, level, rescales
+        offs = sorted(diagonals)
+        stride = S
+        for d in offs:
+            if d:
+                stride = math.gcd(stride, d)
+        m = S // stride
+        ks = [d // stride for d in offs]
+        self.stride = stride
+        self.n1 = max(1, 1 << math.ceil(math.log2(max(2, len(ks))) / 2))
+        self.n1 = min(self.n1, m)
+        self.terms = {}       # g -> list of (b, plaintext)
+        for d, k in zip(offs, ks):
+            g, b = divmod(k, self.n1)
+            shift = g * self.n1 * stride
+            pt = ev.encode(np.roll(diagonals[d], shift), diag_scale, level, S)
+            self.terms.setdefault(g, []).append((b, pt))
+        self.babies = sorted({b for t in self.terms.values() for b, _ in t})
+
+    def steps(self):
+        return [b * self.stride for b in self.babies if b] + [g * self.n1 * self.stride for g in self.terms if g]
+
+    def apply(self, ct):
+        ev = self.ev
+        ct = ev.drop(ct, self.level)
+        rot = dict(zip(self.babies, ev.rotate_many(ct, [b * self.stride for b in self.babies])))
+        total = None
+        for g, terms in self.terms.items():
+            inner = None
+            for b, pt in terms:
+                inner = ev.mul_plain_add(inner, rot[b], pt)
+            if g:
+                inner = ev.rotate(inner, g * self.n1 * self.stride)
+            total = inner if total is None else ev.add(total, inner)
+        for _ in range(self.rescales):
+            total = ev.rescale(total)
+        return total
+
+
 class ChebyshevEvaluator:
     """sum_j c_j T_j(w) with depth ceil(log2(d+1)) + 1 and exact scales: every addition joins
     operands of identical (level, scale) because constants are encoded at the scale that makes the
@@ -185,12 +293,20 @@ class Bootstrapper:
     parts in slots [s, 2s) of ONE ciphertext, so EvalMod runs once.  Otherwise real and imaginary
     parts go through EvalMod as two ciphertexts."""
 
-    def __init__(self, ev, K=12, r=3, degree=31, delta=2.0 ** 40, baby_log=2, packed=None):
+    def __init__(self, ev, K=12, r=3, degree=31, delta=2.0 ** 40, baby_log=2, packed=None,
+                 transform="dense", c2s_groups=3, s2c_groups=3, msg_scale=None):
+        """delta: the scale EvalMod works at (its primes should be close to it); msg_scale: the scale of
+        the ciphertexts to refresh (default delta).  A delta well above msg_scale (say 2^58 against 2^46)
+        lowers the EvalMod noise floor, which full slots see amplified by sqrt(s) * q0 / (2 pi msg_scale)."""
         self.ev, self.K, self.r, self.delta = ev, K, r, delta
+        self.msg_scale = delta if msg_scale is None else msg_scale
         s, n = ev.s, ev.n
         self.s = s
+        self.transform = transform
+        assert transform in ("dense", "fft")
         # packing doubles the dimension of the dense linear transforms: it pays while they are small
-        self.packed = (4 * s <= n and s <= 64) if packed is None else packed
+        self.packed = (4 * s <= n and s <= 64 and transform == "dense") if packed is None else packed
+        assert not (self.packed and transform == "fft"), "the FFT-factored transforms run unpacked"
         assert not self.packed or 4 * s <= n
         S = 2 * s if self.packed else s      # slots of the subring the circuit works in
         self.S, self.g = S, n // (2 * S)
@@ -198,9 +314,33 @@ class Bootstrapper:
         # Chebyshev interpolant of f(w) = cos(2 pi (Kb w - 1/4) / 2^r) on [-1, 1]
         f = lambda w: np.cos(2.0 * np.pi * (self.Kb * w - 0.25) / (1 << r))  # noqa: E731
         self.cheb = ChebyshevEvaluator(ev, np.polynomial.chebyshev.chebinterpolate(f, degree), baby_log)
-        A = slot_matrix(s)
         q0 = ev.q[0]
         norm = 1.0 / (self.g * self.Kb * 2.0)
+        if transform == "fft":
+            self._init_fft(norm, c2s_groups, s2c_groups)
+        else:
+            self._init_dense(norm)
+        steps = set()
+        for t in self.c2s + self.s2c:
+            steps |= set(t.steps())
+        k = S
+        while k < n // 2:
+            steps.add(k)
+            k <<= 1
+        ev.add_rotation_keys(sorted(steps), conj=True)
+
+    def _evalmod_out(self, level):
+        """(scale, level) of the EvalMod output: delta after the polynomial, squared and rescaled by every
+        double angle"""
+        sv, lvl = self.delta, level + self.cheb.depth
+        for _ in range(self.r):
+            sv, lvl = sv * sv / self.ev.q_last(lvl), lvl + 1
+        return sv, lvl
+
+    def _init_dense(self, norm):
+        ev, s, S, r, delta = self.ev, self.s, self.S, self.r, self.delta
+        q0 = ev.q[0]
+        A = slot_matrix(s)
         if self.packed:
             # u' = U z' are the 2s complex coefficient pairs of the 2s-slot subring; the message sits on the
             # even ones: Re u'_{2k} = coefficient k, Im u'_{2k} = coefficient k+s.  v = (u'_{2k}/2, -i u'_{2k}/2)
@@ -217,24 +357,45 @@ class Bootstrapper:
         # integers would otherwise have only ~27 bits) at the scale that turns the re-declared scale q0
         # into delta after both rescales
         c2s_scale = delta * ev.q_last(1) * ev.q_last(2) / q0
-        self.c2s = LinearTransform(ev, c2s_m, 1, c2s_scale, rescales=2)
+        self.c2s = [LinearTransform(ev, c2s_m, 1, c2s_scale, rescales=2)]
         self.evalmod_level = 3
         self.s2c_level = 3 + self.cheb.depth + r
-        # scale of the EvalMod output: delta after the polynomial, squared and rescaled by every double angle
-        sv, lvl = delta, 3 + self.cheb.depth
-        for _ in range(r):
-            sv, lvl = sv * sv / ev.q_last(lvl), lvl + 1
+        sv, _ = self._evalmod_out(3)
         # 1/(2 pi) undoes the sine's factor, q0/delta brings the message back from units of q0 to the
         # working scale: the output is a ciphertext of scale delta again
-        self.s2c = LinearTransform(ev, s2c_m * (q0 / delta) / (2.0 * np.pi), self.s2c_level,
-                                   delta * ev.q_last(self.s2c_level) / sv)
+        self.s2c = [LinearTransform(ev, s2c_m * (q0 / self.msg_scale) / (2.0 * np.pi), self.s2c_level,
+                                   self.msg_scale * ev.q_last(self.s2c_level) / sv)]
         self.out_level = self.s2c_level + 1
-        steps = set(self.c2s.steps()) | set(self.s2c.steps())
-        k = S
-        while k < n // 2:
-            steps.add(k)
-            k <<= 1
-        ev.add_rotation_keys(sorted(steps), conj=True)
+
+    def _init_fft(self, norm, c2s_groups, s2c_groups):
+        """CoeffToSlot / SlotToCoeff as products of merged special-FFT stages: log2(s) stages in
+        c2s_groups (s2c_groups) sparse diagonal maps, one level each, O(groups * 2^(log s / groups))
+        rotations instead of O(sqrt s) with s-diagonal plaintext storage.  The inverse transform leaves
+        the coefficients in bit-reversed slot order, which the slot-wise EvalMod does not see and the
+        forward transform (defined on bit-reversed input) undoes."""
+        ev, S, delta = self.ev, self.S, self.delta
+        q0 = ev.q[0]
+        inv = special_fft_groups(S, min(c2s_groups, max(1, S.bit_length() - 1)), True)
+        fwd = special_fft_groups(S, min(s2c_groups, max(1, S.bit_length() - 1)), False)
+        # intermediate results keep the re-declared scale q0; the last group lands on delta.  The constant
+        # is spread over the groups so that every encoded diagonal has entries of order one.
+        self.c2s, lvl = [], 1
+        cst = norm ** (1.0 / len(inv))
+        for i, g in enumerate(inv):
+            last = i + 1 == len(inv)
+            scale = ev.q_last(lvl) * (delta / q0 if last else 1.0)
+            self.c2s.append(DiagonalTransform(ev, {d: v * cst for d, v in g.items()}, S, lvl, scale))
+            lvl += 1
+        self.evalmod_level = lvl
+        sv, lvl = self._evalmod_out(lvl)
+        self.s2c_level = lvl
+        self.s2c = []
+        cst = ((q0 / self.msg_scale) / (2.0 * np.pi)) ** (1.0 / len(fwd))
+        for i, g in enumerate(fwd):
+            scale = ev.q_last(lvl) * (self.msg_scale / sv if i == 0 else 1.0)
+            self.s2c.append(DiagonalTransform(ev, {d: v * cst for d, v in g.items()}, S, lvl, scale))
+            lvl += 1
+        self.out_level = lvl
 
     def levels_needed(self):
         return self.out_level
@@ -250,7 +411,7 @@ class Bootstrapper:
     def bootstrap(self, ct):
         ev = self.ev
         in_scale = ct.scale
-        assert abs(in_scale / self.delta - 1.0) < 0.01, "the bootstrapper was set up for ciphertexts of scale delta"
+        assert abs(in_scale / self.msg_scale - 1.0) < 0.01, "the bootstrapper was set up for ciphertexts of scale msg_scale"
         q0 = ev.q[0]
         t = ev.mod_raise(ev.drop(ct, ev.bottom))
         t.scale = float(q0)                                   # src/boot/Bootstrapper.cu:2867-2868
@@ -258,7 +419,9 @@ class Bootstrapper:
         while k < ev.n // 2:                                  # SubSum onto the S-slot subring
             t = ev.add(t, ev.rotate(t, k))
             k <<= 1
-        half = self.c2s.apply(t)
+        half = t
+        for lt in self.c2s:
+            half = lt.apply(half)
         cj = ev.conj(half)
         if self.packed:
             v = self.eval_mod(ev.add(half, cj))               # slots [0,s): x_k / Kb, [s,2s): x_{k+s} / Kb
@@ -266,6 +429,8 @@ class Bootstrapper:
             re = ev.add(half, cj)
             im = ev.neg(ev.mul_i(ev.sub(half, cj)))
             v = ev.add(self.eval_mod(re), ev.mul_i(self.eval_mod(im)))   # 2 pi (m_k + i m_{k+s}) / q0
-        out = self.s2c.apply(v)                               # slots: message * in_scale / delta
-        out.scale = out.scale * in_scale / self.delta         # src/boot/Bootstrapper.cu:2933 (a ratio of ~1)
+        out = v
+        for lt in self.s2c:
+            out = lt.apply(out)                           # slots: message * in_scale / delta
+        out.scale = out.scale * in_scale / self.msg_scale         # src/boot/Bootstrapper.cu:2933 (a ratio of ~1)
         return out

@@ -52,6 +52,84 @@ def test_bootstrap_on_the_simulator(orc, pha, s, packed):
     assert np.abs(ev.decrypt_decode(out) - msg).max() < 3e-5
 
 
+def _fft_chain(orc, n, groups, extra=(), d=40, e=None):
+    # q0, two levels left, SlotToCoeff groups, 9 EvalMod levels, CoeffToSlot groups (wide primes: the
+    # stage diagonals multiply q0 * I and their rounding comes back times q0 / delta)
+    return orc.coeff_modulus_create(n, [d + 10] + [d] * 2 + [d] * groups + [e or d] * 9 + [min(60, d + 18)] * groups + list(extra))
+
+
+def test_special_fft_factorisation():
+    """slot_matrix(S) = F_S o .. o F_2 o bitrev, for every grouping of the stages"""
+    from phantom_fhe_amd.bootstrap import slot_matrix, special_fft_groups
+    for S, groups in ((2, 1), (16, 1), (16, 2), (64, 3), (128, 4), (256, 3)):
+        bits = S.bit_length() - 1
+        perm = np.array([int(format(i, "0%db" % bits)[::-1], 2) for i in range(S)])
+        A, j = slot_matrix(S), np.arange(S)
+
+        def dense(maps):
+            m = np.eye(S, dtype=np.complex128)
+            for g in maps:
+                d = np.zeros((S, S), dtype=np.complex128)
+                for off, v in g.items():
+                    d[j, (j + off) % S] += v
+                m = d @ m
+            return m
+        fwd, inv = special_fft_groups(S, groups, False), special_fft_groups(S, groups, True)
+        assert len(fwd) == len(inv) == groups
+        assert np.abs(dense(fwd)[:, perm] - A).max() < 1e-12            # forward stages take bit-reversed input
+        assert np.abs(dense(inv)[perm] - np.linalg.inv(A)).max() < 1e-12    # inverse leaves bit-reversed output
+        # radix-2^k groups: at most 2^(k+1) - 1 diagonals
+        assert max(len(g) for g in fwd + inv) <= 2 ** (-(-bits // groups) + 1) - 1
+
+
+@pytest.mark.parametrize("log_n,s,groups", [(12, 256, 3), (12, 32, 2), (8, 128, 3), (9, 256, 4)])
+def test_fft_bootstrap_on_the_simulator(orc, pha, log_n, s, groups):
+    """FFT-factored CoeffToSlot / SlotToCoeff, sparse and FULL slots (s = N/2: no SubSum)"""
+    from phantom_fhe_amd.bootstrap import Bootstrapper
+    from phantom_fhe_amd.ckks import SimEvaluator
+    n = 1 << log_n
+    q = [int(v) for v in _fft_chain(orc, n, groups)]
+    ev = SimEvaluator(log_n, q, s, hamming_weight=32, seed=s)
+    bs = Bootstrapper(ev, K=12, r=3, degree=31, transform="fft", c2s_groups=groups, s2c_groups=groups)
+    assert bs.levels_needed() == 2 * groups + 10 and not bs.packed
+    rng = np.random.default_rng(1)
+    msg = rng.uniform(-1, 1, s) + 1j * rng.uniform(-1, 1, s)
+    out = bs.bootstrap(ev.encrypt(ev.encode(msg, 2.0 ** 40, ev.bottom)))
+    assert np.abs(ev.last_I).max() >= 3
+    assert out.level == bs.levels_needed() and abs(out.scale / 2.0 ** 40 - 1) < 1e-3
+    assert np.abs(ev.decrypt_decode(out) - msg).max() < 3e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("s,groups,d,e", [(2048, 3, 50, 50), (2048, 4, 40, 58), (128, 2, 40, 40)])
+def test_fft_bootstrap_on_the_gpu(gpu, pha, orc, s, groups, d, e):
+    """full-slot (s = N/2) and sparse bootstrapping through the FFT-factored transforms on real ciphertexts.
+    Full slots work at delta = 2^50: the EvalMod noise floor (about 2^-20 of the sine at delta = 2^40, the
+    rescale / relinearisation noise through 5 squarings of the Chebyshev basis and 3 double angles) comes back
+    times q0 / (2 pi delta) = 163 per coefficient and times sqrt(s) through SlotToCoeff — measured 1.6e-3 at
+    2^40, which sparse packing (SubSum averages it) does not see.  The (40, 58) case keeps 40-bit messages and
+    runs EvalMod alone at 2^58 (msg_scale != delta)."""
+    from phantom_fhe_amd.bootstrap import Bootstrapper
+    from phantom_fhe_amd.ckks import GpuEvaluator
+    mods = _fft_chain(orc, N, groups, extra=[60], d=d, e=e)
+    ctx = pha.PhantomContext(LOG_N, mods, 1)
+    sk = ctx.gen_secretkey(23, hamming_weight=32)
+    ev = GpuEvaluator(pha, ctx, sk, s)
+    bs = Bootstrapper(ev, K=12, r=3, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d, transform="fft", c2s_groups=groups,
+                      s2c_groups=groups)
+    rng = np.random.default_rng(3)
+    msg = rng.uniform(-1, 1, s) + 1j * rng.uniform(-1, 1, s)
+    ct = ev.encrypt(ev.encode(msg, 2.0 ** d, ev.bottom))
+    out = bs.bootstrap(ct)
+    assert out.level == 2 * groups + 10 and ev.limbs(out.level) == 3
+    got = ev.decrypt_decode(out)
+    tol = 1e-3 if e == 40 else 2e-5
+    assert np.abs(got - msg).max() < tol
+    sq = ev.rescale(ev.mul(out, out))
+    assert np.abs(ev.decrypt_decode(sq) - msg * msg).max() < 2 * tol
+    ctx.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("s,packed", [(8, True), (32, True), (16, False)])
 def test_bootstrap_on_the_gpu(gpu, pha, orc, s, packed):

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Sparse-slot CKKS bootstrapping latency at N=2^16 on one GPU (BASELINE config 5's primitive;
-the reference's bootstrap_sparse*, src/boot/Bootstrapper.cu).  Prints one JSON line.
+"""CKKS bootstrapping latency at N=2^16 on one GPU (BASELINE config 5's primitive; the reference's
+bootstrap_sparse* / bootstrap_full*, src/boot/Bootstrapper.cu).  Prints one JSON line.
 
     python tools/bench_bootstrap.py [--slots 64] [--log-n 16] [--reps 3]
+    python tools/bench_bootstrap.py --slots 32768 --transform fft      # full slots, FFT-factored transforms
 """
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,10 +21,19 @@ def main():
     ap.add_argument("--extra-levels", type=int, default=4)
     ap.add_argument("--alpha", type=int, default=4)
     ap.add_argument("--delta-bits", type=int, default=50, help="working scale; q0 has 10 bits more")
+    ap.add_argument("--transform", choices=("dense", "fft"), default="dense")
+    ap.add_argument("--groups", type=int, default=3, help="levels of each FFT-factored transform")
+    ap.add_argument("--evalmod-bits", type=int, default=0, help="EvalMod working scale / primes (default: delta-bits)")
     args = ap.parse_args()
     n = 1 << args.log_n
     d = args.delta_bits
-    q_bits = [d + 10] + [d] * args.extra_levels + [d] + [d] * (9 if args.log_n < 15 else 10) + [d, min(60, d + 18)]
+    e = args.evalmod_bits or d
+    evalmod = [e] * (9 if args.log_n < 15 else 10)
+    if args.transform == "fft":
+        g = min(args.groups, args.slots.bit_length() - 1)
+        q_bits = [d + 10] + [d] * args.extra_levels + [d] * g + evalmod + [min(60, d + 8)] * g
+    else:
+        q_bits = [d + 10] + [d] * args.extra_levels + [d] + evalmod + [d, min(60, d + 18)]
     while len(q_bits) % args.alpha:
         q_bits.insert(1, d)
     mods = pha.coeff_modulus_create(n, q_bits + [60] * args.alpha)
@@ -31,7 +41,8 @@ def main():
     sk = ctx.gen_secretkey(21, hamming_weight=192 if args.log_n >= 15 else 32)
     ev = GpuEvaluator(pha, ctx, sk, args.slots)
     t0 = time.perf_counter()
-    bs = Bootstrapper(ev, K=25 if args.log_n >= 15 else 12, r=3 if args.log_n < 15 else 4, degree=31, delta=2.0 ** d)
+    bs = Bootstrapper(ev, K=25 if args.log_n >= 15 else 12, r=3 if args.log_n < 15 else 4, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d,
+                      transform=args.transform, c2s_groups=args.groups, s2c_groups=args.groups)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     rng = np.random.default_rng(2)
@@ -47,8 +58,8 @@ def main():
         out = bs.bootstrap(ct)
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
-    print(json.dumps({"metric": "sparse-slot CKKS bootstrap ms", "value": 1e3 * min(times), "unit": "ms", "log_n": args.log_n,
-                      "slots": args.slots, "delta_bits": d, "q_limbs": len(q_bits), "special_primes": args.alpha, "levels_after": ev.limbs(out.level) - 1,
+    print(json.dumps({"metric": "CKKS bootstrap ms", "transform": args.transform, "value": 1e3 * min(times), "unit": "ms", "log_n": args.log_n,
+                      "slots": args.slots, "delta_bits": d, "evalmod_bits": e, "q_limbs": len(q_bits), "special_primes": args.alpha, "levels_after": ev.limbs(out.level) - 1,
                       "max_abs_error": err, "setup_s": setup_s, "rotation_keys": len(ev.galois), "n_gpus": 1}), flush=True)
     ctx.close()
 
