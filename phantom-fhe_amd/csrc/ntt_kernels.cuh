@@ -57,6 +57,28 @@ struct Epilogue {
 
 enum : int { EPI_NONE = 0, EPI_SUB_MUL = 1, EPI_SUB_MUL_ADD = 2, EPI_SCALE = 3 };
 
+// Non-temporal result stores (so that no dirty lines wait in the per-XCD L2s for the end-of-kernel write-back)
+// were measured and lost: column kernel 19.0 us against 17.4 us at 72 limbs.  Kept behind a macro for re-measurement.
+#ifndef PHA_NT_STORES
+#define PHA_NT_STORES 0
+#endif
+typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_stream(uint64_t *p, uint64_t v) {
+#if PHA_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st_stream2(uint64_t *p, ulonglong2 v) {
+#if PHA_NT_STORES
+    u64x2_t w = {v.x, v.y};
+    __builtin_nontemporal_store(w, reinterpret_cast<u64x2_t *>(p));
+#else
+    *reinterpret_cast<ulonglong2 *>(p) = v;
+#endif
+}
+
 // returns false when this workgroup has nothing to do (ragged last digit)
 __device__ __forceinline__ bool resolve_limb(const LimbMap &m, uint32_t poly, uint32_t li, uint32_t &twr, uint32_t &tidx) {
     uint32_t es = m.excl_start, ee = m.excl_end;
@@ -198,7 +220,7 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, uint64_t *base, con
         for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(lds[lds_col<C, RB>((r_hi << RB) | j, c)]);
         ct_radix<RB, RA>(x, CanonTw<TW>{tw, (1u << RA) + r_hi}, f);
 #pragma unroll
-        for (int j = 0; j < (1 << RB); j++) base[static_cast<size_t>((r_hi << RB) | j) * n2 + c] = F::raw(x[j]);
+        for (int j = 0; j < (1 << RB); j++) st_stream(&base[static_cast<size_t>((r_hi << RB) | j) * n2 + c], F::raw(x[j]));
     }
 }
 
@@ -244,6 +266,18 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, uint64_t *base, con
         for (int j = 0; j < (1 << RA); j++) lds[lds_row(a * L + ((j << RB) | b_lo))] = F::raw(x[j]);
     }
     __syncthreads();
+    // the epilogue's operands are fetched here, a whole pass ahead of their use: loaded inside the store loop
+    // they cannot move above the previous iteration's store (out may alias them) and every iteration pays a
+    // full memory round trip (measured: 40.8 us against 17.4 us for the plain kernel at 72 limbs)
+    ulonglong2 pre_s[EPI != EPI_NONE ? 8 : 1], pre_a[EPI == EPI_SUB_MUL_ADD ? 8 : 1];
+    if (EPI != EPI_NONE) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t e = (i * kThreads + t) * 2;
+            pre_s[i] = *reinterpret_cast<const ulonglong2 *>(sub + e);
+            if (EPI == EPI_SUB_MUL_ADD) pre_a[i] = *reinterpret_cast<const ulonglong2 *>(addend + e);
+        }
+    }
 #pragma unroll
     for (int g = 0; g < GD; g++) {
         const uint32_t gid = t + kThreads * g, e0 = gid << RB;
@@ -268,19 +302,17 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, uint64_t *base, con
         if (EPI != EPI_NONE) {
             // (cx - NTT(delta)) * PInv mod q  (src/ntt/ntt_moddown.cu:209-214,
             // include/uintmodmath.cuh:234-242); same shape for rescale (src/rns.cu:1138-1155)
-            const ulonglong2 s = *reinterpret_cast<const ulonglong2 *>(sub + e);
-            v.x = f.to_u64(f.sub_mul(v0, s.x, c));
-            v.y = f.to_u64(f.sub_mul(v1, s.y, c));
+            v.x = f.to_u64(f.sub_mul(v0, pre_s[i].x, c));
+            v.y = f.to_u64(f.sub_mul(v1, pre_s[i].y, c));
             if (EPI == EPI_SUB_MUL_ADD) {
-                const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(addend + e);
-                v.x = csub(v.x + a.x, q);
-                v.y = csub(v.y + a.y, q);
+                v.x = csub(v.x + pre_a[i].x, q);
+                v.y = csub(v.y + pre_a[i].y, q);
             }
         } else {
             v.x = f.to_u64(v0);
             v.y = f.to_u64(v1);
         }
-        *reinterpret_cast<ulonglong2 *>(out + e) = v;
+        st_stream2(out + e, v);
     }
 }
 
@@ -358,7 +390,7 @@ __device__ __forceinline__ void intt_row_body(uint64_t *lds, uint64_t *dst, cons
         for (int j = 0; j < (1 << RA); j++) x[j] = F::unraw(lds[lds_row(a * L + ((j << RB) | b_lo))]);
         gs_radix<RA, false>(x, CanonTw<TW>{tw, n1 + ti * RW + a}, f, unused);
 #pragma unroll
-        for (int j = 0; j < (1 << RA); j++) dst[a * L + ((j << RB) | b_lo)] = F::raw(x[j]);
+        for (int j = 0; j < (1 << RA); j++) st_stream(&dst[a * L + ((j << RB) | b_lo)], F::raw(x[j]));
     }
 }
 
@@ -417,7 +449,7 @@ __device__ __forceinline__ void intt_col_body(uint64_t *lds, uint64_t *base, con
             typename F::elem v = x[j];
             // fused bconv phase 1 (src/ntt/ntt_modup.cu:212-318)
             if (EPI == EPI_SCALE) v = f.scale(v, c_scale);
-            base[static_cast<size_t>((j << RB) | r_lo) * n2 + c] = f.to_u64(v);
+            st_stream(&base[static_cast<size_t>((j << RB) | r_lo) * n2 + c], f.to_u64(v));
         }
     }
 }
