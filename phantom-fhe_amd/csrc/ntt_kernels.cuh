@@ -18,9 +18,30 @@
 
 namespace pha {
 
-constexpr int kTile = 4096;
-constexpr int kThreads = 256;
+// One workgroup transforms a tile of kTile coefficients, 16 per thread: 4096 (256 threads), four workgroups per CU.
+// Measured alternatives at configs[1] (1152 workgroups = 4.5 per CU; per-workgroup timestamps from
+// tools/scratch/trace_ntt.py show the last 128 running as a second generation that ends ~3.5 us after the first):
+//  * PHA_TILE_LOG=11 (128 threads, 16 KiB LDS, eight to nine workgroups per CU): row kernels unchanged (18.1 us),
+//    column kernels 23.3 us against 17.4 us — their global accesses shrink to half cache lines;
+//  * PHA_LDS_SWIZZLE=1 (unpadded 32 KiB image, 96 VGPRs) does NOT reach five workgroups per CU: a CU hands out
+//    LDS to five workgroups only up to 31 KiB each (tools/scratch/occ.hip: 31744 B -> 5 resident, 32256 B -> 4).
+// Both stay selectable for re-measurement; every variant passes the parity tests.
+#ifndef PHA_TILE_LOG
+#define PHA_TILE_LOG 12
+#endif
+constexpr int kTileLog = PHA_TILE_LOG;
+constexpr int kTile = 1 << kTileLog;
+constexpr int kThreads = kTile / 16;
+#ifndef PHA_LDS_SWIZZLE
+#define PHA_LDS_SWIZZLE (PHA_TILE_LOG < 12)
+#endif
+#if PHA_LDS_SWIZZLE
+constexpr int kLdsWords = kTile;
+#define PHA_NTT_BOUNDS __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5)))
+#else
 constexpr int kLdsWords = kTile + 512;
+#define PHA_NTT_BOUNDS __launch_bounds__(kThreads)
+#endif
 
 struct LimbMap {
     uint32_t start, count;          // buffer limbs [start, start+count)
@@ -78,6 +99,17 @@ __device__ __forceinline__ void st_stream2(uint64_t *p, ulonglong2 v) {
     *reinterpret_cast<ulonglong2 *>(p) = v;
 #endif
 }
+
+// Development aid (tools/scratch/trace_ntt.py): per-workgroup timestamps of the forward kernels' phases.
+#ifdef PHA_TRACE
+__device__ unsigned long long *pha_trace_buf;
+#define PHA_TRACE_MARK(slot)                                                                      \
+    do {                                                                                          \
+        if (threadIdx.x == 0 && pha_trace_buf) pha_trace_buf[blockIdx.x * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define PHA_TRACE_MARK(slot)
+#endif
 
 // returns false when this workgroup has nothing to do (ragged last digit)
 __device__ __forceinline__ bool resolve_limb(const LimbMap &m, uint32_t poly, uint32_t li, uint32_t &twr, uint32_t &tidx) {
@@ -173,17 +205,30 @@ __device__ __forceinline__ void gs_radix(typename F::elem (&x)[1 << R], const Tw
     }
 }
 
-// LDS images are padded against bank conflicts (measured: an unpadded XOR-swizzled 32 KiB image
-// that admits five workgroups per CU was not faster).
-// Column tile [row][C cols]: with C = 16 a row is half a 256-B bank row; shift every 2^RB-row
-// group by one row so that the second pass's half-waves hit both halves.
+// LDS images: padded (36 KiB, default) or XOR-swizzled (32 KiB) against bank conflicts.
+// Column tile [row][C cols]: with C = 16 a row is half a 256-B bank row; the second pass's half-waves are 2^RB
+// rows apart and must hit both halves (padded: every 2^RB-row group shifted by one row).
 template <int C, int RB>
 __device__ __forceinline__ uint32_t lds_col(uint32_t r, uint32_t c) {
+#if PHA_LDS_SWIZZLE
+    // rows 2^RB apart (the lanes of the second pass's half-waves) land in different parts of a 256-B bank row
+    constexpr uint32_t mask = C < 32 ? 32 / C - 1 : 0;      // rows per 256-B bank row, minus one
+    return (r ^ ((r >> RB) & mask)) * C + c;
+#else
     return r * C + c + (C == 16 ? (r >> RB) * 16 : 0);
+#endif
 }
-// Row tile: 16 B of padding per 128 B so that the last pass's ds_read_b128 (lane stride 128 B)
-// is conflict-free.
-__device__ __forceinline__ uint32_t lds_row(uint32_t e) { return e + ((e >> 4) << 1); }
+// Row tile, seen as 128-B rows of eight 16-B chunks.  Padded: 16 B per 128 B so that the last pass's ds_read_b128
+// (lane stride 128 B) is conflict-free.  Swizzled: chunk ^= (row >> 1) & 7 spreads the 16 lanes of such a read
+// over the 16 chunks of a bank row, and row ^= (row >> 4) & 1 separates the first pass's half-waves (16 rows apart).
+__device__ __forceinline__ uint32_t lds_row(uint32_t e) {
+#if PHA_LDS_SWIZZLE
+    const uint32_t row = e >> 4;
+    return ((row ^ ((row >> 4) & 1u)) << 4) | (((e >> 1) ^ (row >> 1)) & 7u) << 1 | (e & 1u);
+#else
+    return e + ((e >> 4) << 1);
+#endif
+}
 
 // Between the two kernels of a transform the buffer holds the field's raw lazy representation
 // (an unreduced integer, or the bits of a double on the FP64 path); only the first kernel's
@@ -201,6 +246,7 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, uint64_t *base, con
     using TW = typename F::twl;
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
     const uint32_t t = threadIdx.x;
+    PHA_TRACE_MARK(0);
 #pragma unroll
     for (int g = 0; g < GA; g++) {
         const uint32_t gid = t + kThreads * g, c = gid % C, r_lo = gid / C;
@@ -211,7 +257,9 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, uint64_t *base, con
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) lds[lds_col<C, RB>((j << RB) | r_lo, c)] = F::raw(x[j]);
     }
+    PHA_TRACE_MARK(1);
     __syncthreads();
+    PHA_TRACE_MARK(2);
 #pragma unroll
     for (int g = 0; g < GB; g++) {
         const uint32_t gid = t + kThreads * g, c = gid % C, r_hi = gid / C;
@@ -222,13 +270,18 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, uint64_t *base, con
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) st_stream(&base[static_cast<size_t>((r_hi << RB) | j) * n2 + c], F::raw(x[j]));
     }
+    PHA_TRACE_MARK(3);
+#ifdef PHA_TRACE
+    __builtin_amdgcn_s_waitcnt(0);      // stores acknowledged
+    PHA_TRACE_MARK(4);
+#endif
 }
 
 template <int S1, int RA, bool NARROW>
-__global__ __launch_bounds__(kThreads) void fntt_col_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm) {
+__global__ PHA_NTT_BOUNDS void fntt_col_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm) {
     constexpr int C = kTile >> S1;
     __shared__ uint64_t lds[kLdsWords];
-    const uint32_t n = 1u << T.log_n, n2 = n >> S1, tiles = n >> 12;
+    const uint32_t n = 1u << T.log_n, n2 = n >> S1, tiles = n >> kTileLog;
     uint32_t poly, tile;
     decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
     const uint32_t li = tile / tiles, ti = tile % tiles;
@@ -266,18 +319,6 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, uint64_t *base, con
         for (int j = 0; j < (1 << RA); j++) lds[lds_row(a * L + ((j << RB) | b_lo))] = F::raw(x[j]);
     }
     __syncthreads();
-    // the epilogue's operands are fetched here, a whole pass ahead of their use: loaded inside the store loop
-    // they cannot move above the previous iteration's store (out may alias them) and every iteration pays a
-    // full memory round trip (measured: 40.8 us against 17.4 us for the plain kernel at 72 limbs)
-    ulonglong2 pre_s[EPI != EPI_NONE ? 8 : 1], pre_a[EPI == EPI_SUB_MUL_ADD ? 8 : 1];
-    if (EPI != EPI_NONE) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint32_t e = (i * kThreads + t) * 2;
-            pre_s[i] = *reinterpret_cast<const ulonglong2 *>(sub + e);
-            if (EPI == EPI_SUB_MUL_ADD) pre_a[i] = *reinterpret_cast<const ulonglong2 *>(addend + e);
-        }
-    }
 #pragma unroll
     for (int g = 0; g < GD; g++) {
         const uint32_t gid = t + kThreads * g, e0 = gid << RB;
@@ -302,11 +343,14 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, uint64_t *base, con
         if (EPI != EPI_NONE) {
             // (cx - NTT(delta)) * PInv mod q  (src/ntt/ntt_moddown.cu:209-214,
             // include/uintmodmath.cuh:234-242); same shape for rescale (src/rns.cu:1138-1155)
-            v.x = f.to_u64(f.sub_mul(v0, pre_s[i].x, c));
-            v.y = f.to_u64(f.sub_mul(v1, pre_s[i].y, c));
+            // (fetching these operands a pass ahead was measured: no gain, and 64 more VGPRs)
+            const ulonglong2 s = *reinterpret_cast<const ulonglong2 *>(sub + e);
+            v.x = f.to_u64(f.sub_mul(v0, s.x, c));
+            v.y = f.to_u64(f.sub_mul(v1, s.y, c));
             if (EPI == EPI_SUB_MUL_ADD) {
-                v.x = csub(v.x + pre_a[i].x, q);
-                v.y = csub(v.y + pre_a[i].y, q);
+                const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(addend + e);
+                v.x = csub(v.x + a.x, q);
+                v.y = csub(v.y + a.y, q);
             }
         } else {
             v.x = f.to_u64(v0);
@@ -317,10 +361,10 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, uint64_t *base, con
 }
 
 template <int S2, int RA, int EPI, bool NARROW>
-__global__ __launch_bounds__(kThreads) void fntt_row_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm,
+__global__ PHA_NTT_BOUNDS void fntt_row_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm,
                                                             Epilogue ep) {
     __shared__ uint64_t lds[kLdsWords];
-    const uint32_t n = 1u << T.log_n, n1 = n >> S2, tiles = n >> 12;
+    const uint32_t n = 1u << T.log_n, n1 = n >> S2, tiles = n >> kTileLog;
     uint32_t poly, tile;
     decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
     const uint32_t li = tile / tiles, ti = tile % tiles;
@@ -395,10 +439,10 @@ __device__ __forceinline__ void intt_row_body(uint64_t *lds, uint64_t *dst, cons
 }
 
 template <int S2, int RA>
-__global__ __launch_bounds__(kThreads) void intt_row_kernel(uint64_t *out, const uint64_t *in, size_t poly_stride,
+__global__ PHA_NTT_BOUNDS void intt_row_kernel(uint64_t *out, const uint64_t *in, size_t poly_stride,
                                                             NttTables T, LimbMap lm) {
     __shared__ uint64_t lds[kLdsWords];
-    const uint32_t n = 1u << T.log_n, n1 = n >> S2, tiles = n >> 12;
+    const uint32_t n = 1u << T.log_n, n1 = n >> S2, tiles = n >> kTileLog;
     uint32_t poly, tile;
     decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
     const uint32_t li = tile / tiles, ti = tile % tiles;
@@ -455,11 +499,11 @@ __device__ __forceinline__ void intt_col_body(uint64_t *lds, uint64_t *base, con
 }
 
 template <int S1, int RA, int EPI>
-__global__ __launch_bounds__(kThreads) void intt_col_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm,
+__global__ PHA_NTT_BOUNDS void intt_col_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm,
                                                             Epilogue ep) {
     constexpr int C = kTile >> S1;
     __shared__ uint64_t lds[kLdsWords];
-    const uint32_t n = 1u << T.log_n, n2 = n >> S1, tiles = n >> 12;
+    const uint32_t n = 1u << T.log_n, n2 = n >> S1, tiles = n >> kTileLog;
     uint32_t poly, tile;
     decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
     const uint32_t li = tile / tiles, ti = tile % tiles;

@@ -312,7 +312,7 @@ void launch_icol(int epi, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, 
 int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stride, const NttRange &r, int epi,
                 const Epilogue &ep, hipStream_t st, int phases = 3) {
     if (!r.active || !polys) return PHA_OK;
-    const dim3 grid(r.active * static_cast<uint32_t>(ctx->n >> 12) * static_cast<uint32_t>(polys));
+    const dim3 grid(r.active * static_cast<uint32_t>(ctx->n >> kTileLog) * static_cast<uint32_t>(polys));
     const NttTables T = ctx->fwd_tables();
     NttRange rr = r;
     rr.lm.polys = static_cast<uint32_t>(polys);
@@ -330,7 +330,7 @@ int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stri
 int ntt_backward(pha_context *ctx, uint64_t *out, const uint64_t *in, size_t polys, size_t poly_stride,
                  const NttRange &r, int epi, const Epilogue &ep, hipStream_t st, int phases = 3) {
     if (!r.active || !polys) return PHA_OK;
-    const dim3 grid(r.active * static_cast<uint32_t>(ctx->n >> 12) * static_cast<uint32_t>(polys));
+    const dim3 grid(r.active * static_cast<uint32_t>(ctx->n >> kTileLog) * static_cast<uint32_t>(polys));
     const NttTables T = ctx->inv_tables();
     NttRange rr = r;
     rr.lm.polys = static_cast<uint32_t>(polys);
@@ -1603,5 +1603,14 @@ int pha_gen_secretkey_sparse(pha_context *ctx, uint64_t seed, size_t hamming_wei
     PHA_TRY(make_range(ctx, L, 0, 0, 0, 0, 0, r));
     return ntt_forward(ctx, sk, 1, 0, r, EPI_NONE, Epilogue{}, st);
 }
+
+#ifdef PHA_TRACE
+// development aid: see PHA_TRACE_MARK in ntt_kernels.cuh
+int pha_set_trace(uint64_t *buf) {
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(buf);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pha::pha_trace_buf), &p, sizeof(p)));
+    return PHA_OK;
+}
+#endif
 
 }  // extern "C"
