@@ -186,6 +186,8 @@ struct IntField {
         return csub(csub(csub(v, m.q4), m.q << 1), m.q);
     }
     __device__ __forceinline__ void gs(elem &x, elem &y, const twt &w) const { gs_butterfly4(x, y, w, m); }
+    // inverse lazy range [0,4q) -> [0,q)
+    __device__ __forceinline__ elem canon_inv(elem v) const { return csub(csub(v, m.q << 1), m.q); }
     // last inverse stage: the sum half takes N^-1, the difference half takes itw[1] (which
     // already holds N^-1, src/util/ntt.cu:53-55); exact-quotient Shoup lands in [0,q)
     __device__ __forceinline__ void gs_last(elem &x, elem &y, const twt &w, const twt &n_inv) const {
@@ -261,6 +263,7 @@ struct FpField {
         y = u - t;
     }
     __device__ __forceinline__ elem canon_fwd(elem v) const { return canon(v); }
+    __device__ __forceinline__ elem canon_inv(elem v) const { return canon(v); }
     // Inverse butterfly: inputs |.| <= 2q -> |d| <= 4q <= 2^52, sum reduced to <= q/2+1, product
     // <= (1/2 + 1.5 * 4q / 2^52) q <= 2q
     __device__ __forceinline__ void gs(elem &x, elem &y, const twt &w) const {

@@ -65,6 +65,8 @@ struct NttTables {
     uint32_t twD_stride;   // records per limb in twD
     uint32_t fp64;         // limbs with q < 2^50 run on FpField; their table regions hold one double w per
                            // twiddle (8-byte records in the same order, first half of the region)
+    uint32_t split;        // N = 2^17: 1 = the outermost radix-2 stage runs in its own kernel (split_*_kernel) and
+                           // the column kernels transform the two halves as subtrees rooted at twiddle nodes 2, 3
 };
 
 // out[l][e] = (sub[l][e] - x) * cst[l] (+ addend[l][e])   or   x * cst[l]
@@ -233,6 +235,18 @@ __device__ __forceinline__ uint32_t lds_row(uint32_t e) {
 // Between the two kernels of a transform the buffer holds the field's raw lazy representation
 // (an unreduced integer, or the bits of a double on the FP64 path); only the first kernel's
 // input and the last kernel's output are residues in the caller's format.
+// Geometry of a column tile: the 2^split subtrees of a limb are independent column transforms on n >> split
+// consecutive coefficients, rooted at twiddle node 2^split + h.
+struct SubTree {
+    uint32_t offset, tile, n2, root;
+};
+template <int S1>
+__device__ __forceinline__ SubTree sub_tree(const NttTables &T, uint32_t ti) {
+    const uint32_t n_sub = (1u << T.log_n) >> T.split, tiles_sub = n_sub >> kTileLog;
+    const uint32_t h = ti / tiles_sub;
+    return SubTree{h * n_sub, ti % tiles_sub, n_sub >> S1, (1u << T.split) + h};
+}
+
 __device__ __forceinline__ bool use_fp64(const NttTables &T, const DModulus &mod) {
     return T.fp64 && (mod.value >> 50) == 0;
 }
@@ -241,7 +255,8 @@ __device__ __forceinline__ bool use_fp64(const NttTables &T, const DModulus &mod
 // forward, column phase: stages m = 1 .. 2^(S1-1)
 // ---------------------------------------------------------------------------------------------
 template <int S1, int RA, class F>
-__device__ __forceinline__ void fntt_col_body(uint64_t *lds, uint64_t *base, const tw_t *tw_raw, uint32_t n2, const F &f) {
+__device__ __forceinline__ void fntt_col_body(uint64_t *lds, uint64_t *base, const tw_t *tw_raw, uint32_t n2, uint32_t root,
+                                              const F &f) {
     constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
     using TW = typename F::twl;
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
@@ -253,7 +268,7 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, uint64_t *base, con
         typename F::elem x[1 << RA];
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) x[j] = f.from_u64(base[static_cast<size_t>((j << RB) | r_lo) * n2 + c]);
-        ct_radix<RA, 0>(x, CanonTw<TW>{tw, 1u}, f);
+        ct_radix<RA, 0>(x, CanonTw<TW>{tw, root}, f);
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) lds[lds_col<C, RB>((j << RB) | r_lo, c)] = F::raw(x[j]);
     }
@@ -266,7 +281,7 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, uint64_t *base, con
         typename F::elem x[1 << RB];
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(lds[lds_col<C, RB>((r_hi << RB) | j, c)]);
-        ct_radix<RB, RA>(x, CanonTw<TW>{tw, (1u << RA) + r_hi}, f);
+        ct_radix<RB, RA>(x, CanonTw<TW>{tw, (root << RA) + r_hi}, f);
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) st_stream(&base[static_cast<size_t>((r_hi << RB) | j) * n2 + c], F::raw(x[j]));
     }
@@ -281,19 +296,20 @@ template <int S1, int RA, bool NARROW>
 __global__ PHA_NTT_BOUNDS void fntt_col_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm) {
     constexpr int C = kTile >> S1;
     __shared__ uint64_t lds[kLdsWords];
-    const uint32_t n = 1u << T.log_n, n2 = n >> S1, tiles = n >> kTileLog;
+    const uint32_t n = 1u << T.log_n, tiles = n >> kTileLog;
     uint32_t poly, tile;
     decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
     const uint32_t li = tile / tiles, ti = tile % tiles;
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, li, twr, tidx)) return;
-    uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + ti * C;
+    const SubTree st = sub_tree<S1>(T, ti);
+    uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + st.offset + st.tile * C;
     const DModulus mod = T.mod[tidx];
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     if (use_fp64(T, mod))
-        fntt_col_body<S1, RA>(lds, base, tw, n2, FpField(mod));
+        fntt_col_body<S1, RA>(lds, base, tw, st.n2, st.root, FpField(mod));
     else
-        fntt_col_body<S1, RA>(lds, base, tw, n2, IntField<NARROW>(mod));
+        fntt_col_body<S1, RA>(lds, base, tw, st.n2, st.root, IntField<NARROW>(mod));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -461,9 +477,10 @@ __global__ PHA_NTT_BOUNDS void intt_row_kernel(uint64_t *out, const uint64_t *in
 // ---------------------------------------------------------------------------------------------
 // inverse, column phase (last): stages m = 2^(S1-1) .. 1, N^-1, reduction to [0,q), optional scale
 // ---------------------------------------------------------------------------------------------
-template <int S1, int RA, int EPI, class F>
-__device__ __forceinline__ void intt_col_body(uint64_t *lds, uint64_t *base, const tw_t *tw_raw, uint32_t n2, const F &f,
-                                              uint64_t n_inv, uint64_t n_inv_shoup, uint64_t cst, uint64_t cst_shoup) {
+template <int S1, int RA, int EPI, bool SPLIT, class F>
+__device__ __forceinline__ void intt_col_body(uint64_t *lds, uint64_t *base, const tw_t *tw_raw, uint32_t n2, uint32_t root,
+                                              const F &f, uint64_t n_inv, uint64_t n_inv_shoup, uint64_t cst,
+                                              uint64_t cst_shoup) {
     constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
     using TW = typename F::twl;
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
@@ -475,7 +492,7 @@ __device__ __forceinline__ void intt_col_body(uint64_t *lds, uint64_t *base, con
         typename F::elem x[1 << RB];
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(base[static_cast<size_t>((r_hi << RB) | j) * n2 + c]);
-        gs_radix<RB, false>(x, CanonTw<TW>{tw, (1u << RA) + r_hi}, f, ninv);
+        gs_radix<RB, false>(x, CanonTw<TW>{tw, (root << RA) + r_hi}, f, ninv);
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) lds[lds_col<C, RB>((r_hi << RB) | j, c)] = F::raw(x[j]);
     }
@@ -487,10 +504,13 @@ __device__ __forceinline__ void intt_col_body(uint64_t *lds, uint64_t *base, con
         typename F::elem x[1 << RA];
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) x[j] = F::unraw(lds[lds_col<C, RB>((j << RB) | r_lo, c)]);
-        gs_radix<RA, true>(x, CanonTw<TW>{tw, 1u}, f, ninv);
+        if (SPLIT)      // a subtree: its last stage is an ordinary one; N^-1 waits for split_inv_kernel
+            gs_radix<RA, false>(x, CanonTw<TW>{tw, root}, f, ninv);
+        else
+            gs_radix<RA, true>(x, CanonTw<TW>{tw, 1u}, f, ninv);
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) {
-            typename F::elem v = x[j];
+            typename F::elem v = SPLIT ? f.canon_inv(x[j]) : x[j];
             // fused bconv phase 1 (src/ntt/ntt_modup.cu:212-318)
             if (EPI == EPI_SCALE) v = f.scale(v, c_scale);
             st_stream(&base[static_cast<size_t>((j << RB) | r_lo) * n2 + c], f.to_u64(v));
@@ -498,18 +518,19 @@ __device__ __forceinline__ void intt_col_body(uint64_t *lds, uint64_t *base, con
     }
 }
 
-template <int S1, int RA, int EPI>
+template <int S1, int RA, int EPI, bool SPLIT = false>
 __global__ PHA_NTT_BOUNDS void intt_col_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm,
                                                             Epilogue ep) {
     constexpr int C = kTile >> S1;
     __shared__ uint64_t lds[kLdsWords];
-    const uint32_t n = 1u << T.log_n, n2 = n >> S1, tiles = n >> kTileLog;
+    const uint32_t n = 1u << T.log_n, tiles = n >> kTileLog;
     uint32_t poly, tile;
     decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
     const uint32_t li = tile / tiles, ti = tile % tiles;
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, li, twr, tidx)) return;
-    uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + ti * C;
+    const SubTree st = sub_tree<S1>(T, ti);
+    uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + st.offset + st.tile * C;
     const DModulus mod = T.mod[tidx];
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     const uint64_t n_inv = T.n_inv[tidx], n_inv_shoup = T.n_inv_shoup[tidx];
@@ -519,9 +540,71 @@ __global__ PHA_NTT_BOUNDS void intt_col_kernel(uint64_t *data, size_t poly_strid
         cst_shoup = ep.cst_shoup[twr];
     }
     if (use_fp64(T, mod))
-        intt_col_body<S1, RA, EPI>(lds, base, tw, n2, FpField(mod), n_inv, n_inv_shoup, cst, cst_shoup);
+        intt_col_body<S1, RA, EPI, SPLIT>(lds, base, tw, st.n2, st.root, FpField(mod), n_inv, n_inv_shoup, cst, cst_shoup);
     else
-        intt_col_body<S1, RA, EPI>(lds, base, tw, n2, IntField<true>(mod), n_inv, n_inv_shoup, cst, cst_shoup);
+        intt_col_body<S1, RA, EPI, SPLIT>(lds, base, tw, st.n2, st.root, IntField<true>(mod), n_inv, n_inv_shoup, cst,
+                                          cst_shoup);
+}
+
+// ---------------------------------------------------------------------------------------------
+// N = 2^17: the outermost radix-2 stage (m = 1, pairs N/2 apart) as an element-wise kernel on canonical
+// residues; Barrett products, so the same code serves integer and FP64 limbs.  One workgroup = 4096 pairs.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t root_twiddle(const NttTables &T, const DModulus &mod, const tw_t *tw) {
+    // tw[1]: FP64 limbs store doubles, integer limbs {w, w_shoup}
+    return use_fp64(T, mod) ? static_cast<uint64_t>(reinterpret_cast<const double *>(tw)[1]) : tw[1].x;
+}
+
+__global__ __launch_bounds__(256) void split_fwd_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm) {
+    const uint32_t n = 1u << T.log_n, half = n >> 1, tiles = half >> 12;
+    uint32_t poly, tile;
+    decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
+    const uint32_t li = tile / tiles, ti = tile % tiles;
+    uint32_t twr, tidx;
+    if (!resolve_limb(lm, poly, li, twr, tidx)) return;
+    uint64_t *lo = data + poly * poly_stride + static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * 4096, *hi = lo + half;
+    const DModulus mod = T.mod[tidx];
+    const uint64_t q = mod.value, w = root_twiddle(T, mod, T.tw + static_cast<size_t>(tidx) * n);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t e = (i * 256 + threadIdx.x) * 2;
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(lo + e), b = *reinterpret_cast<const ulonglong2 *>(hi + e);
+        // inputs may be lazy (< 4q) like the reference's; Barrett reduces any 64-bit value
+        const uint64_t a0 = barrett64(a.x, q, mod.ratio1), a1 = barrett64(a.y, q, mod.ratio1);
+        const uint64_t t0 = mul_barrett(b.x, w, mod), t1 = mul_barrett(b.y, w, mod);
+        *reinterpret_cast<ulonglong2 *>(lo + e) = ulonglong2{csub(a0 + t0, q), csub(a1 + t1, q)};
+        *reinterpret_cast<ulonglong2 *>(hi + e) = ulonglong2{csub(a0 + q - t0, q), csub(a1 + q - t1, q)};
+    }
+}
+
+// inverse: x = (a + b) N^-1, y = (a - b) itw[1] (itw[1] already holds N^-1, src/util/ntt.cu:53-55), optional scale
+template <int EPI>
+__global__ __launch_bounds__(256) void split_inv_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm,
+                                                        Epilogue ep) {
+    const uint32_t n = 1u << T.log_n, half = n >> 1, tiles = half >> 12;
+    uint32_t poly, tile;
+    decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
+    const uint32_t li = tile / tiles, ti = tile % tiles;
+    uint32_t twr, tidx;
+    if (!resolve_limb(lm, poly, li, twr, tidx)) return;
+    uint64_t *lo = data + poly * poly_stride + static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * 4096, *hi = lo + half;
+    const DModulus mod = T.mod[tidx];
+    const uint64_t q = mod.value, w = root_twiddle(T, mod, T.tw + static_cast<size_t>(tidx) * n);
+    const uint64_t n_inv = T.n_inv[tidx];
+    const uint64_t cst = EPI == EPI_SCALE ? ep.cst[twr] : 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t e = (i * 256 + threadIdx.x) * 2;
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(lo + e), b = *reinterpret_cast<const ulonglong2 *>(hi + e);
+        ulonglong2 x{mul_barrett(csub(a.x + b.x, q), n_inv, mod), mul_barrett(csub(a.y + b.y, q), n_inv, mod)};
+        ulonglong2 y{mul_barrett(csub(a.x + q - b.x, q), w, mod), mul_barrett(csub(a.y + q - b.y, q), w, mod)};
+        if (EPI == EPI_SCALE) {
+            x = ulonglong2{mul_barrett(x.x, cst, mod), mul_barrett(x.y, cst, mod)};
+            y = ulonglong2{mul_barrett(y.x, cst, mod), mul_barrett(y.y, cst, mod)};
+        }
+        *reinterpret_cast<ulonglong2 *>(lo + e) = x;
+        *reinterpret_cast<ulonglong2 *>(hi + e) = y;
+    }
 }
 
 }  // namespace pha

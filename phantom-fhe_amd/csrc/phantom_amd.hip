@@ -52,14 +52,16 @@ int fail(int code, const char *fmt, ...) {
 // NTT decomposition per log N: S1 column stages (first pass radix 2^RA1), S2 row stages
 struct NttPlan {
     int s1, ra1, s2, ra2;
+    int split;  // 1: the outermost radix-2 stage runs in its own kernel (N = 2^17)
 };
 bool plan_for(int log_n, NttPlan &p) {
     switch (log_n) {
-        case 12: p = {6, 3, 6, 3}; return true;
-        case 13: p = {6, 3, 7, 4}; return true;
-        case 14: p = {7, 4, 7, 4}; return true;
-        case 15: p = {7, 4, 8, 4}; return true;
-        case 16: p = {8, 4, 8, 4}; return true;
+        case 12: p = {6, 3, 6, 3, 0}; return true;
+        case 13: p = {6, 3, 7, 4, 0}; return true;
+        case 14: p = {7, 4, 7, 4, 0}; return true;
+        case 15: p = {7, 4, 8, 4, 0}; return true;
+        case 16: p = {8, 4, 8, 4, 0}; return true;
+        case 17: p = {8, 4, 8, 4, 1}; return true;
         default: return false;
     }
 }
@@ -139,11 +141,11 @@ struct pha_context {
 
     NttTables fwd_tables() const {
         return NttTables{d_mod.p, d_tw.p, d_twD.p, d_n_inv.p, d_n_inv_shoup.p, static_cast<uint32_t>(log_n), twD_stride,
-                         fp64 ? 1u : 0u};
+                         fp64 ? 1u : 0u, static_cast<uint32_t>(plan.split)};
     }
     NttTables inv_tables() const {
         return NttTables{d_mod.p, d_itw.p, d_itwD.p, d_n_inv.p, d_n_inv_shoup.p, static_cast<uint32_t>(log_n), twD_stride,
-                         fp64 ? 1u : 0u};
+                         fp64 ? 1u : 0u, static_cast<uint32_t>(plan.split)};
     }
     bool limb_is_fp64(size_t l) const { return fp64 && (moduli[l] >> 50) == 0; }
 };
@@ -296,6 +298,16 @@ void launch_irow(dim3 grid, hipStream_t st, uint64_t *out, const uint64_t *in, s
 template <int S, int RA>
 void launch_icol(int epi, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, const NttTables &T, const LimbMap &lm,
                  const Epilogue &ep) {
+    if (T.split) {
+        // subtrees only (instantiated for the N = 2^17 plan); N^-1 and the epilogue follow in split_inv_kernel
+        hipLaunchKernelGGL((intt_col_kernel<8, 4, EPI_NONE, true>), grid, dim3(kThreads), 0, st, data, ps, T, lm, ep);
+        const dim3 g2(grid.x >> (13 - kTileLog));
+        if (epi == EPI_SCALE)
+            hipLaunchKernelGGL((split_inv_kernel<EPI_SCALE>), g2, dim3(256), 0, st, data, ps, T, lm, ep);
+        else
+            hipLaunchKernelGGL((split_inv_kernel<EPI_NONE>), g2, dim3(256), 0, st, data, ps, T, lm, ep);
+        return;
+    }
     if (epi == EPI_SCALE)
         hipLaunchKernelGGL((intt_col_kernel<S, RA, EPI_SCALE>), grid, dim3(kThreads), 0, st, data, ps, T, lm, ep);
     else
@@ -316,6 +328,9 @@ int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stri
     const NttTables T = ctx->fwd_tables();
     NttRange rr = r;
     rr.lm.polys = static_cast<uint32_t>(polys);
+    if ((phases & 1) && T.split)
+        hipLaunchKernelGGL(split_fwd_kernel, dim3(r.active * static_cast<uint32_t>(ctx->n >> 13) * static_cast<uint32_t>(polys)), dim3(256), 0, st,
+                           data, poly_stride, T, rr.lm);
     if (phases & 1)
     DISPATCH_S(ctx->plan.s1, 0, (launch_fcol<6, 3>(ctx->narrow, grid, st, data, poly_stride, T, rr.lm)),
                (launch_fcol<7, 4>(ctx->narrow, grid, st, data, poly_stride, T, rr.lm)),

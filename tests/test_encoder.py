@@ -71,10 +71,13 @@ def test_gpu_encoder_errors(gpu, pha, orc):
 
 
 @pytest.mark.gpu
-def test_gpu_ckks_pipeline_slotwise(gpu, pha, orc):
-    """encode -> encrypt -> HMult+relin -> rescale -> rotate -> conjugate -> decrypt -> decode."""
-    mods = orc.coeff_modulus_create(N, [60, 40, 40, 40, 60])
-    ctx = pha.PhantomContext(LOG_N, mods, 1)
+@pytest.mark.parametrize("LOG_N,special", [(12, 1), (17, 2)])
+def test_gpu_ckks_pipeline_slotwise(gpu, pha, orc, LOG_N, special):
+    """encode -> encrypt -> HMult+relin -> rescale -> rotate -> conjugate -> decrypt -> decode; also at the largest
+    supported degree N = 2^17 with full slots (65536)."""
+    N = 1 << LOG_N
+    mods = orc.coeff_modulus_create(N, [60, 40, 40, 40] + [60] * special)
+    ctx = pha.PhantomContext(LOG_N, mods, special)
     sk = ctx.gen_secretkey(5)
     rlk = ctx.gen_relinkey(sk, 6)
     s = N // 2
@@ -92,15 +95,19 @@ def test_gpu_ckks_pipeline_slotwise(gpu, pha, orc):
     ctx.rescale_to_next(1, prod[:2].contiguous(), 2, res)
     new_scale = scale * scale / float(mods[3])
     got = ctx.decode(ctx.ckks_decrypt(sk, res, 2), new_scale, s, 2)
-    assert np.abs(got - z1 * z2).max() < 1e-5                    # the reference's tests ask for << 1e-3
+    # the reference's tests ask for << 1e-3.  The rescale is the reference's FLOOR division (src/rns.cu:1125-1181):
+    # its +1/2 mean per coefficient is a constant polynomial bias that lands on the slots whose root is nearest 1
+    # (slot 0: 8e-6 at N = 2^16, 2.2e-5 at 2^17; the median slot error is 1e-8)
+    tol = 1e-5 if LOG_N == 12 else 1e-4
+    assert np.abs(got - z1 * z2).max() < tol and np.median(np.abs(got - z1 * z2)) < 1e-6
     # rotation by 3 slots at level 2, then complex conjugation
     step = 3
     elt = pha.galois_elt_from_step(LOG_N, step)
     ctx.apply_galois_inplace(2, res, elt, ctx.gen_galois_key(sk, elt, 7))
     got = ctx.decode(ctx.ckks_decrypt(sk, res, 2), new_scale, s, 2)
-    assert np.abs(got - np.roll(z1 * z2, -step)).max() < 1e-5
+    assert np.abs(got - np.roll(z1 * z2, -step)).max() < tol
     conj = 2 * N - 1
     ctx.apply_galois_inplace(2, res, conj, ctx.gen_galois_key(sk, conj, 8))
     got = ctx.decode(ctx.ckks_decrypt(sk, res, 2), new_scale, s, 2)
-    assert np.abs(got - np.conj(np.roll(z1 * z2, -step))).max() < 1e-5
+    assert np.abs(got - np.conj(np.roll(z1 * z2, -step))).max() < tol
     ctx.close()

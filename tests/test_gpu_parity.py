@@ -21,7 +21,7 @@ def small(gpu, pha, orc):
     return pha.PhantomContext(12, mods, 2), orc.Oracle(12, mods, 2)
 
 
-@pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16])
+@pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])
 def test_ntt_forward_backward_all_sizes(gpu, pha, orc, log_n):
     n = 1 << log_n
     mods = orc.coeff_modulus_create(n, [60, 50, 40, 60])
@@ -41,6 +41,39 @@ def test_ntt_forward_backward_all_sizes(gpu, pha, orc, log_n):
     ctx.nwt_2d_radix8_forward_inplace(d, 2, 1)
     got = _host(pha, d)
     assert (got[1:3] == ref[1:3]).all() and (got[0] == x[0]).all() and (got[3] == x[3]).all()
+    ctx.close()
+
+
+def test_n131072_key_switch_rescale_galois(gpu, pha, orc):
+    """N = 2^17 (the reference's largest SAMPLE_SIZE case, include/ntt.cuh:19): the outermost stage runs in its own
+    kernel and the column kernels work on two subtrees — every fused variant of the transform (scale epilogue in the
+    modup INTT, moddown and rescale epilogues, digit exclusion, special-modulus indices) goes through that plan."""
+    log_n, n, size_p = 17, 1 << 17, 2
+    mods = orc.coeff_modulus_create(n, [45] * 4 + [55] * size_p)        # FP64 limbs and integer limbs
+    ctx, o = pha.PhantomContext(log_n, mods, size_p), orc.Oracle(log_n, mods, size_p)
+    size_ql = 4
+    x = o.uniform_poly([0], 1)
+    ref = x.copy()
+    o.nwt_forward_inplace(ref, 1, 0)
+    d = _dev(pha, x + np.uint64(3 * int(o.moduli[0])))                  # lazy input
+    ctx.nwt_2d_radix8_forward_inplace(d, 1, 0)
+    assert (_host(pha, d) == ref).all()
+    evk_h, evk_d = _uniform_evk(pha, o, 170)
+    c2 = o.uniform_poly(list(range(size_ql)), 6)
+    ct = np.stack([o.uniform_poly(list(range(size_ql)), 7), o.uniform_poly(list(range(size_ql)), 8)])
+    ct_ref = ct.copy()
+    o.keyswitch_inplace(size_ql, ct_ref, c2, evk_h)
+    d_ct = _dev(pha, ct)
+    ctx.keyswitch_inplace(1, d_ct, _dev(pha, c2), evk_d)
+    assert (_host(pha, d_ct) == ct_ref).all()
+    ref = o.divide_and_round_q_last_ntt(size_ql, ct, 2)
+    d_dst = _dev(pha, np.zeros_like(ref))
+    ctx.rescale_to_next(1, _dev(pha, ct), 2, d_dst)
+    assert (_host(pha, d_dst) == ref).all()
+    elt = pha.galois_elt_from_step(log_n, 3)
+    d_out = _dev(pha, np.zeros_like(ct[0]))
+    ctx.apply_galois_ntt(_dev(pha, ct[0]), size_ql, elt, d_out)
+    assert (_host(pha, d_out) == o.apply_galois_ntt(ct[0], elt)).all()
     ctx.close()
 
 
