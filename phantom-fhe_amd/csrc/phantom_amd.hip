@@ -1479,7 +1479,8 @@ int pha_ckks_encode(pha_context *ctx, const double *values_host, size_t values_s
     pha_context::EncoderLevel *lv;
     PHA_TRY(get_encoder_level(ctx, limbs, &lv));
     if (!(scale > 0) || static_cast<int>(std::log2(scale)) + 1 >= lv->total_bits)
-        return fail(PHA_ERR_INVALID_ARGUMENT, "scale out of bounds");
+        return fail(PHA_ERR_INVALID_ARGUMENT, "scale out of bounds (encode: scale %g, %d modulus bits at chain index %zu)", scale,
+                    lv->total_bits, chain_index);
     size_t s = sparse_slots;
     if (s == 0)
         for (s = 1; s < values_size; s <<= 1) {}
@@ -1527,7 +1528,9 @@ int pha_ckks_decode(pha_context *ctx, const uint64_t *plain, size_t chain_index,
     PHA_TRY(level_limbs(ctx, chain_index, &limbs));
     pha_context::EncoderLevel *lv;
     PHA_TRY(get_encoder_level(ctx, limbs, &lv));
-    if (!(scale > 0) || static_cast<int>(std::log2(scale)) >= lv->total_bits) return fail(PHA_ERR_INVALID_ARGUMENT, "scale out of bounds");
+    if (!(scale > 0) || static_cast<int>(std::log2(scale)) >= lv->total_bits)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "scale out of bounds (decode: scale %g, %d modulus bits at chain index %zu)", scale,
+                    lv->total_bits, chain_index);
     PHA_TRY(check_slots(ctx, sparse_slots));
     hipStream_t st = as_stream(stream);
     const uint32_t n = static_cast<uint32_t>(ctx->n), S = static_cast<uint32_t>(sparse_slots);

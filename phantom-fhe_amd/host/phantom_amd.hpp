@@ -10,12 +10,14 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <cstdint>
 #include <cstdlib>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <random>
 #include <stdexcept>
 #include <string>
@@ -51,34 +53,84 @@ public:
     const hipStream_t &get_stream() const { return stream_; }
 };
 
-// RAII device buffer of uint64_t words
+// Stream-ordered recycling of temporaries (the role of the reference's cudaMallocAsync pool with an unlimited
+// release threshold, include/cuda_wrapper.cuh:141-186, src/context.cu:130-135): a buffer released on stream s is
+// handed to the next request of the same size on the SAME stream, whose work is enqueued after the previous
+// owner's — no driver call, no synchronisation.  (hipMallocAsync / hipFreeAsync were measured first: a
+// full-slot bootstrap at N = 2^16 left the GPU idle for a quarter of its 53 ms.)  Buffers are kept until exit.
+class device_pool {
+    std::map<std::pair<hipStream_t, size_t>, std::vector<uint64_t *>> free_;
+    std::mutex m_;
+
+public:
+    static device_pool &instance() {
+        static device_pool *p = new device_pool;  // never destroyed: the HIP runtime may be gone at exit
+        return *p;
+    }
+    uint64_t *take(size_t n, hipStream_t s) {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            auto it = free_.find({s, n});
+            if (it != free_.end() && !it->second.empty()) {
+                uint64_t *p = it->second.back();
+                it->second.pop_back();
+                return p;
+            }
+        }
+        uint64_t *p = nullptr;
+        check_hip(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(uint64_t)), "hipMalloc");
+        return p;
+    }
+    void give(uint64_t *p, size_t n, hipStream_t s) {
+        std::lock_guard<std::mutex> g(m_);
+        free_[{s, n}].push_back(p);
+    }
+};
+
+// RAII device buffer of uint64_t words.  With a stream it comes from / returns to the stream-ordered pool;
+// the release is ordered on the stream of the last set_stream().
 class device_words {
     uint64_t *p_ = nullptr;
     size_t n_ = 0;
+    hipStream_t stream_ = nullptr;
+    bool pooled_ = false;
 
 public:
     device_words() = default;
     explicit device_words(size_t n) { reset(n); }
+    device_words(size_t n, hipStream_t stream) : n_(n), stream_(stream), pooled_(true) {
+        if (n) p_ = device_pool::instance().take(n, stream);
+    }
     ~device_words() { release(); }
     device_words(const device_words &) = delete;
     device_words &operator=(const device_words &) = delete;
-    device_words(device_words &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr, o.n_ = 0; }
+    device_words(device_words &&o) noexcept : p_(o.p_), n_(o.n_), stream_(o.stream_), pooled_(o.pooled_) { o.p_ = nullptr, o.n_ = 0; }
     device_words &operator=(device_words &&o) noexcept {
         if (this != &o) {
             release();
-            p_ = o.p_, n_ = o.n_;
+            p_ = o.p_, n_ = o.n_, stream_ = o.stream_, pooled_ = o.pooled_;
             o.p_ = nullptr, o.n_ = 0;
         }
         return *this;
     }
     void release() {
-        if (p_) (void)hipFree(p_);
+        if (p_) {
+            if (pooled_)
+                device_pool::instance().give(p_, n_, stream_);
+            else
+                (void)hipFree(p_);
+        }
         p_ = nullptr, n_ = 0;
     }
     void reset(size_t n) {
         release();
+        pooled_ = false;
         if (n) check_hip(hipMalloc(reinterpret_cast<void **>(&p_), n * sizeof(uint64_t)), "hipMalloc");
         n_ = n;
+    }
+    // later work on `stream` has used the buffer: release it in that stream's order
+    void set_stream(hipStream_t stream) {
+        if (pooled_) stream_ = stream;
     }
     uint64_t *get() const { return p_; }
     size_t size() const { return n_; }
@@ -100,8 +152,16 @@ class EncryptionParameters {
     size_t poly_modulus_degree_ = 0;
     std::vector<uint64_t> coeff_modulus_;
     size_t special_modulus_size_ = 1;  // include/util/encryptionparams.h:375
+    size_t secret_key_hamming_weight_ = 0, sparse_slots_ = 0;
 
 public:
+    EncryptionParameters() = default;
+    explicit EncryptionParameters(int /*scheme_type::ckks*/) {}
+    // 0 = dense ternary key; h > 0: exactly h non-zero coefficients (src/secretkey.cu:401-433)
+    void set_secret_key_hamming_weight(size_t h) { secret_key_hamming_weight_ = h; }
+    void set_sparse_slots(size_t s) { sparse_slots_ = s; }
+    size_t secret_key_hamming_weight() const { return secret_key_hamming_weight_; }
+    size_t sparse_slots() const { return sparse_slots_; }
     void set_poly_modulus_degree(size_t n) { poly_modulus_degree_ = n; }
     void set_coeff_modulus(const std::vector<uint64_t> &m) { coeff_modulus_ = m; }
     void set_special_modulus_size(size_t s) { special_modulus_size_ = s; }
@@ -169,17 +229,40 @@ public:
     void resize(size_t size, size_t coeff_modulus_size, size_t poly_modulus_degree, const hipStream_t &stream) {
         const size_t words = size * coeff_modulus_size * poly_modulus_degree;
         if (words != data_.size()) {
-            device_words fresh(words);
+            device_words fresh(words, stream);
             const size_t keep = std::min(words, data_.size());
             if (keep)
                 check_hip(hipMemcpyAsync(fresh.get(), data_.get(), keep * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream),
                           "hipMemcpyAsync");
             if (words > keep)
                 check_hip(hipMemsetAsync(fresh.get() + keep, 0, (words - keep) * sizeof(uint64_t), stream), "hipMemsetAsync");
-            check_hip(hipStreamSynchronize(stream), "hipStreamSynchronize");  // old buffer is freed below
+            data_.set_stream(stream);  // the old buffer is freed after the copy, in stream order
             data_ = std::move(fresh);
         }
         size_ = size, coeff_modulus_size_ = coeff_modulus_size, poly_modulus_degree_ = poly_modulus_degree;
+    }
+    // uninitialised storage for an operation's destination (no copy, no memset)
+    void allocate(const PhantomContext &context, size_t chain_index, size_t size, const hipStream_t &stream) {
+        const size_t limbs = context.coeff_mod_size(chain_index), n = context.poly_degree();
+        data_.set_stream(stream);
+        data_ = device_words(size * limbs * n, stream);
+        size_ = size, coeff_modulus_size_ = limbs, poly_modulus_degree_ = n, chain_index_ = chain_index;
+    }
+    // the first `size` polys of a larger buffer (after relinearisation), without reallocating
+    void truncate(size_t size) {
+        if (size > size_) throw std::invalid_argument("truncate cannot grow a ciphertext");
+        size_ = size;
+    }
+    // every later use of this ciphertext on `stream` orders the eventual free after it
+    void touch(const hipStream_t &stream) { data_.set_stream(stream); }
+    PhantomCiphertext clone(const hipStream_t &stream) const {
+        PhantomCiphertext c;
+        c.data_ = device_words(size_ * coeff_modulus_size_ * poly_modulus_degree_, stream);
+        check_hip(hipMemcpyAsync(c.data_.get(), data_.get(), size_ * coeff_modulus_size_ * poly_modulus_degree_ * sizeof(uint64_t),
+                                 hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync");
+        c.size_ = size_, c.coeff_modulus_size_ = coeff_modulus_size_, c.poly_modulus_degree_ = poly_modulus_degree_;
+        c.chain_index_ = chain_index_, c.scale_ = scale_, c.is_ntt_form_ = is_ntt_form_;
+        return c;
     }
     uint64_t *data() const { return data_.get(); }
     size_t size() const { return size_; }
@@ -251,7 +334,19 @@ class PhantomCKKSEncoder {
     size_t slots_ = 0, sparse_slots_ = 0;
 
 public:
-    explicit PhantomCKKSEncoder(const PhantomContext &context) : slots_(context.poly_degree() >> 1) {}
+    explicit PhantomCKKSEncoder(const PhantomContext &context)
+        : slots_(context.poly_degree() >> 1), sparse_slots_(context.key_parms().sparse_slots()) {}
+    // encode on an explicit slot count (a power of two <= N/2) without touching the encoder's own sparse_slots:
+    // what the bootstrapper's diagonals and constants need
+    void encode_slots(const PhantomContext &context, const std::vector<std::complex<double>> &values, size_t sparse_slots,
+                      double scale, PhantomPlaintext &destination, size_t chain_index, const hip_stream_wrapper &stream_wrapper) {
+        const hipStream_t &s = stream_wrapper.get_stream();
+        destination.resize(context.coeff_mod_size(chain_index), context.poly_degree(), s);
+        check(pha_ckks_encode(context.handle(), reinterpret_cast<const double *>(values.data()), values.size(), sparse_slots,
+                              chain_index, scale, destination.data(), s));
+        destination.set_chain_index(chain_index);
+        destination.set_scale(scale);
+    }
     size_t slot_count() const { return slots_; }
     size_t sparse_slots() const { return sparse_slots_; }
     void reset_sparse_slots() { sparse_slots_ = 0; }
@@ -327,7 +422,11 @@ public:
     void gen_secretkey(const PhantomContext &context, const hipStream_t &stream) {
         if (gen_flag_) throw std::logic_error("cannot generate secret key twice");
         sk_ = device_words(context.key_parms().coeff_modulus().size() * context.poly_degree());
-        check(pha_gen_secretkey(context.handle(), next_seed(), sk_.get(), stream));
+        const size_t h = context.key_parms().secret_key_hamming_weight();
+        if (h)
+            check(pha_gen_secretkey_sparse(context.handle(), next_seed(), h, sk_.get(), stream));
+        else
+            check(pha_gen_secretkey(context.handle(), next_seed(), sk_.get(), stream));
         gen_flag_ = true;
     }
     PhantomRelinKey gen_relinkey(const PhantomContext &context, const hip_stream_wrapper &sw) {
@@ -341,6 +440,12 @@ public:
             gk.insert(e, make_key(context, 1, e, sw.get_stream()));
         }
         return gk;
+    }
+    // add the keys of `elts` that `gk` does not hold yet
+    void add_galois_keys_from_elts(const PhantomContext &context, const std::vector<uint32_t> &elts, PhantomGaloisKey &gk,
+                                   const hip_stream_wrapper &sw) {
+        for (uint32_t e : elts)
+            if (!gk.has(e)) gk.insert(e, make_key(context, 1, e, sw.get_stream()));
     }
     PhantomGaloisKey create_galois_keys_from_steps(const PhantomContext &context, const std::vector<int> &steps,
                                                    const hip_stream_wrapper &sw) {

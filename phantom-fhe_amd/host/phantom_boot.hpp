@@ -1,0 +1,711 @@
+// CKKS bootstrapping on the C++ host layer (phantom_amd.hpp): the reference's CKKSEvaluator
+// (include/boot/ckks_evaluator.cuh) and Bootstrapper (include/boot/Bootstrapper.cuh, src/boot/Bootstrapper.cu)
+// with the constructor and the calls of examples/bootstrapping.cu —
+//
+//     CKKSEvaluator ckks(&context, &secret_key, &encoder, &relin_keys, &galois_keys, scale);
+//     Bootstrapper boot(loge, logn, logN - 1, total_level, scale, boundary_K, deg, scale_factor, inverse_deg, &ckks);
+//     boot.prepare_mod_polynomial();
+//     boot.addLeftRotKeys_Linear_to_vector_3(gal_steps_vector);
+//     ckks.create_galois_keys_from_steps(gal_steps_vector);
+//     boot.slot_vec.push_back(logn);
+//     boot.generate_LT_coefficient_3();
+//     boot.bootstrap_3(rtn, cipher);
+//
+// The circuit is this repository's (the Python twin is phantom-fhe_amd/bootstrap.py):
+// ModRaise, SubSum, CoeffToSlot and SlotToCoeff as three merged groups of special-FFT stages each
+// (the "_3" = three levels per linear transform of the reference), EvalMod as a Chebyshev interpolant of
+// the scaled cosine evaluated by Paterson-Stockmeyer with exact scales plus `scale_factor` double
+// angles.  No NTL / Remez files: the polynomial is interpolated in double precision.  Every
+// polynomial operation is a C-ABI call; this header only sequences them and keeps (level, scale).
+//
+// Parameter guidance (differs from the reference, whose EvalMod is tuned for q0 / scale = 2^5..2^10 with an
+// arcsine stage): q0 about 2^10 x scale, EvalMod primes wide (58 bit) for full slots; chain from the top:
+// 3 CoeffToSlot primes (58-60 bit), depth + scale_factor EvalMod primes, 3 SlotToCoeff primes, then the
+// remaining levels; `loge`, `L` and `inverse_deg` are accepted for signature compatibility and not used.
+#pragma once
+
+#include <functional>
+#include <numeric>
+#include <set>
+#include <tuple>
+
+#include "phantom_amd.hpp"
+
+namespace phantom {
+
+using cvec = std::vector<std::complex<double>>;
+using DiagMap = std::map<int, cvec>;  // rotation offset d -> diagonal v:  x -> sum_d v_d * rot(x, d)
+
+// =====================================================================================================
+// CKKSEvaluator: out-of-place operations with (chain_index, scale) bookkeeping
+// =====================================================================================================
+class CKKSEvaluator {
+public:
+    PhantomContext *context;
+    PhantomSecretKey *secret_key;
+    PhantomCKKSEncoder *encoder;
+    PhantomRelinKey *relin_keys;
+    PhantomGaloisKey *galois_keys;
+    double scale;
+    hip_stream_wrapper stream;
+
+private:
+    std::map<std::tuple<double, double, double, size_t>, PhantomPlaintext> consts_;
+    std::map<size_t, device_words> mono_;
+    const hipStream_t &s() const { return stream.get_stream(); }
+    pha_context *h() const { return context->handle(); }
+    static void same(const PhantomCiphertext &a, const PhantomCiphertext &b) {
+        if (a.chain_index() != b.chain_index()) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+        if (std::abs(a.scale() / b.scale() - 1.0) > 1e-9) throw std::invalid_argument("scale mismatch");
+    }
+    PhantomCiphertext make(size_t level, double sc) {
+        PhantomCiphertext c;
+        c.allocate(*context, level, 2, s());
+        c.set_scale(sc);
+        return c;
+    }
+
+public:
+    CKKSEvaluator(PhantomContext *context_, PhantomSecretKey *secret_key_, PhantomCKKSEncoder *encoder_,
+                  PhantomRelinKey *relin_keys_, PhantomGaloisKey *galois_keys_, double scale_)
+        : context(context_), secret_key(secret_key_), encoder(encoder_), relin_keys(relin_keys_), galois_keys(galois_keys_),
+          scale(scale_) {}
+
+    size_t n() const { return context->poly_degree(); }
+    size_t limbs(size_t level) const { return context->coeff_mod_size(level); }
+    double q(size_t i) const { return static_cast<double>(context->modulus(i)); }
+    double q_last(size_t level) const { return q(limbs(level) - 1); }  // the prime a rescale at `level` divides by
+    size_t bottom() const { return context->size_Q(); }
+    void sync() const { check_hip(hipStreamSynchronize(s()), "hipStreamSynchronize"); }
+
+    // ---- keys (ckks_evaluator.decryptor.create_galois_keys_from_steps, examples/bootstrapping.cu:145) --------
+    void create_galois_keys_from_steps(const std::vector<int> &steps, bool conjugate = true) {
+        std::vector<uint32_t> elts;
+        const int half = static_cast<int>(n() >> 1);
+        for (int st : steps) {
+            if (st % half == 0) continue;
+            uint32_t e;
+            check(pha_galois_elt_from_step(context->log_n(), st, &e));
+            elts.push_back(e);
+        }
+        if (conjugate) elts.push_back(static_cast<uint32_t>(2 * n() - 1));
+        secret_key->add_galois_keys_from_elts(*context, elts, *galois_keys, stream);
+    }
+
+    // ---- encode / encrypt / decrypt --------------------------------------------------------------------
+    PhantomPlaintext encode(const cvec &values, double sc, size_t level, size_t slots) {
+        PhantomPlaintext p;
+        encoder->encode_slots(*context, values, slots, sc, p, level, stream);
+        return p;
+    }
+    PhantomCiphertext encrypt(const PhantomPlaintext &p) {
+        PhantomCiphertext c;
+        secret_key->encrypt_symmetric(*context, p, c, stream);
+        c.set_chain_index(p.chain_index());
+        return c;
+    }
+    cvec decrypt_decode(const PhantomCiphertext &c, size_t slots) {
+        PhantomPlaintext p;
+        secret_key->decrypt(*context, c, p, stream);
+        cvec out(slots);
+        check(pha_ckks_decode(h(), p.data(), p.chain_index(), p.scale(), slots, reinterpret_cast<double *>(out.data()), s()));
+        return out;
+    }
+
+    // ---- arithmetic -----------------------------------------------------------------------------------
+    PhantomCiphertext add(const PhantomCiphertext &a, const PhantomCiphertext &b) {
+        same(a, b);
+        PhantomCiphertext d = make(a.chain_index(), a.scale());
+        check(pha_add_rns_poly(h(), d.data(), a.data(), b.data(), a.coeff_modulus_size(), 2, 2, s()));
+        return d;
+    }
+    void add_inplace(PhantomCiphertext &a, const PhantomCiphertext &b) {
+        same(a, b);
+        check(pha_add_rns_poly(h(), a.data(), a.data(), b.data(), a.coeff_modulus_size(), 2, 2, s()));
+    }
+    PhantomCiphertext sub(const PhantomCiphertext &a, const PhantomCiphertext &b) {
+        same(a, b);
+        PhantomCiphertext d = make(a.chain_index(), a.scale());
+        check(pha_sub_rns_poly(h(), d.data(), a.data(), b.data(), a.coeff_modulus_size(), 2, 2, s()));
+        return d;
+    }
+    PhantomCiphertext neg(const PhantomCiphertext &a) {
+        PhantomCiphertext d = make(a.chain_index(), a.scale());
+        check(pha_negate_rns_poly(h(), d.data(), a.data(), a.coeff_modulus_size(), 2, s()));
+        return d;
+    }
+    PhantomCiphertext add_plain(const PhantomCiphertext &a, const PhantomPlaintext &p) {
+        if (a.chain_index() != p.chain_index() || std::abs(a.scale() / p.scale() - 1.0) > 1e-9)
+            throw std::invalid_argument("encrypted and plain parameter mismatch");
+        PhantomCiphertext d = a.clone(s());
+        check(pha_add_rns_poly(h(), d.data(), d.data(), p.data(), d.coeff_modulus_size(), 1, 1, s()));
+        return d;
+    }
+    PhantomCiphertext mul_plain(const PhantomCiphertext &a, const PhantomPlaintext &p) {
+        if (a.chain_index() != p.chain_index()) throw std::invalid_argument("encrypted and plain parameter mismatch");
+        PhantomCiphertext d = make(a.chain_index(), a.scale() * p.scale());
+        check(pha_multiply_rns_poly(h(), d.data(), a.data(), p.data(), a.coeff_modulus_size(), 2, 1, s()));
+        return d;
+    }
+    // acc += a * p in one pass (multiply_and_add_rns_poly); an empty acc is initialised with a * p
+    void mul_plain_add(PhantomCiphertext &acc, const PhantomCiphertext &a, const PhantomPlaintext &p) {
+        if (acc.data() == nullptr) {
+            acc = mul_plain(a, p);
+            return;
+        }
+        if (a.chain_index() != p.chain_index() || a.chain_index() != acc.chain_index() ||
+            std::abs(acc.scale() / (a.scale() * p.scale()) - 1.0) > 1e-9)
+            throw std::invalid_argument("multiply-accumulate parameter mismatch");
+        check(pha_multiply_add_rns_poly(h(), acc.data(), a.data(), p.data(), acc.data(), a.coeff_modulus_size(), 2, 1, s()));
+    }
+    // HMult + relinearise (multiply_inplace + relinearize_inplace of the reference's evaluator)
+    PhantomCiphertext mul(const PhantomCiphertext &a, const PhantomCiphertext &b) {
+        if (a.chain_index() != b.chain_index()) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+        PhantomCiphertext d;
+        d.allocate(*context, a.chain_index(), 3, s());
+        const size_t words = 2 * a.coeff_modulus_size() * n();
+        check_hip(hipMemcpyAsync(d.data(), a.data(), words * sizeof(uint64_t), hipMemcpyDeviceToDevice, s()), "hipMemcpyAsync");
+        check(pha_multiply_and_relin_inplace(h(), a.chain_index(), d.data(), b.data(), relin_keys->public_keys_ptr(), s()));
+        d.truncate(2);
+        d.set_scale(a.scale() * b.scale());
+        return d;
+    }
+    PhantomCiphertext rescale(const PhantomCiphertext &a) {
+        PhantomCiphertext d = make(a.chain_index() + 1, a.scale() / q_last(a.chain_index()));
+        check(pha_rescale_to_next(h(), a.chain_index(), a.data(), 2, d.data(), s()));
+        return d;
+    }
+    // CKKS mod_switch_to: drop limbs, no scaling (src/evaluate.cu:618-700) — one strided copy per poly
+    PhantomCiphertext drop(const PhantomCiphertext &a, size_t level) {
+        if (level < a.chain_index()) throw std::invalid_argument("cannot switch to higher level modulus");
+        if (level == a.chain_index()) return a.clone(s());
+        PhantomCiphertext d = make(level, a.scale());
+        const size_t src = a.coeff_modulus_size() * n(), dst = d.coeff_modulus_size() * n();
+        check_hip(hipMemcpy2DAsync(d.data(), dst * sizeof(uint64_t), a.data(), src * sizeof(uint64_t), dst * sizeof(uint64_t), 2,
+                                   hipMemcpyDeviceToDevice, s()), "hipMemcpy2DAsync");
+        return d;
+    }
+    // a at `level` without a copy when it is already there
+    const PhantomCiphertext &at_level(const PhantomCiphertext &a, size_t level, PhantomCiphertext &tmp) {
+        if (level == a.chain_index()) return a;
+        tmp = drop(a, level);
+        return tmp;
+    }
+
+    // ---- constants (a constant vector is the constant polynomial: two slots are enough; cached) --------------
+    const PhantomPlaintext &const_pt(std::complex<double> c, double sc, size_t level) {
+        const auto key = std::make_tuple(c.real(), c.imag(), sc, level);
+        auto it = consts_.find(key);
+        if (it == consts_.end()) it = consts_.emplace(key, encode(cvec{c, c}, sc, level, 2)).first;
+        return it->second;
+    }
+    PhantomCiphertext add_const(const PhantomCiphertext &a, double c) { return add_plain(a, const_pt(c, a.scale(), a.chain_index())); }
+    PhantomCiphertext mul_const(const PhantomCiphertext &a, double c, double const_scale) {
+        return mul_plain(a, const_pt(c, const_scale, a.chain_index()));
+    }
+    PhantomCiphertext dbl(const PhantomCiphertext &a) { return add(a, a); }
+    // exact (level, scale): multiply by the constant 1 encoded at the scale that makes the rescaled product land on it
+    PhantomCiphertext to_level_scale(const PhantomCiphertext &a, size_t level, double sc) {
+        if (a.chain_index() >= level) throw std::invalid_argument("to_level_scale needs a level to spend");
+        PhantomCiphertext tmp;
+        const PhantomCiphertext &x = at_level(a, level - 1, tmp);
+        return rescale(mul_const(x, 1.0, sc * q_last(level - 1) / x.scale()));
+    }
+    // 2a^2 - 1: a Chebyshev doubling / a cosine double angle, one level
+    PhantomCiphertext square_double_minus_one(const PhantomCiphertext &a) {
+        PhantomCiphertext t = mul(a, a);
+        add_inplace(t, t);
+        return add_const(rescale(t), -1.0);
+    }
+
+    // ---- rotations ---------------------------------------------------------------------------------------
+    uint32_t elt(int step) const {
+        uint32_t e;
+        check(pha_galois_elt_from_step(context->log_n(), step, &e));
+        return e;
+    }
+    // all rotations of one ciphertext share its modup (pha_rotate_hoisted); steps that are multiples of N/2 copy
+    std::vector<PhantomCiphertext> rotate_many(const PhantomCiphertext &a, const std::vector<int> &steps) {
+        const int half = static_cast<int>(n() >> 1);
+        std::vector<PhantomCiphertext> out(steps.size());
+        std::vector<uint32_t> elts;
+        std::vector<const uint64_t *const *> evks;
+        std::vector<uint64_t *> dst;
+        for (size_t i = 0; i < steps.size(); i++) {
+            if (steps[i] % half == 0) {
+                out[i] = a.clone(s());
+                continue;
+            }
+            out[i] = make(a.chain_index(), a.scale());
+            elts.push_back(elt(steps[i]));
+            evks.push_back(galois_keys->get_relin_keys(elts.back()).public_keys_ptr());
+            dst.push_back(out[i].data());
+        }
+        if (!elts.empty())
+            check(pha_rotate_hoisted(h(), a.chain_index(), a.data(), elts.size(), elts.data(), evks.data(), dst.data(), s()));
+        return out;
+    }
+    PhantomCiphertext rotate(const PhantomCiphertext &a, int step) {
+        PhantomCiphertext d = a.clone(s());
+        if (step % static_cast<int>(n() >> 1) == 0) return d;
+        const uint32_t e = elt(step);
+        check(pha_apply_galois_inplace(h(), d.chain_index(), d.data(), e, galois_keys->get_relin_keys(e).public_keys_ptr(), s()));
+        return d;
+    }
+    PhantomCiphertext conj(const PhantomCiphertext &a) {
+        PhantomCiphertext d = a.clone(s());
+        const uint32_t e = static_cast<uint32_t>(2 * n() - 1);
+        check(pha_apply_galois_inplace(h(), d.chain_index(), d.data(), e, galois_keys->get_relin_keys(e).public_keys_ptr(), s()));
+        return d;
+    }
+    // multiplication of every slot by i = multiplication of the polynomial by X^(N/2): exact
+    PhantomCiphertext mul_i(const PhantomCiphertext &a) {
+        const size_t l = a.coeff_modulus_size();
+        auto it = mono_.find(l);
+        if (it == mono_.end()) {
+            std::vector<uint64_t> host(l * n(), 0);
+            for (size_t j = 0; j < l; j++) host[j * n() + n() / 2] = 1;
+            device_words m(l * n());
+            check_hip(hipMemcpy(m.get(), host.data(), host.size() * sizeof(uint64_t), hipMemcpyHostToDevice), "hipMemcpy");
+            check(pha_nwt_2d_radix8_forward_inplace(h(), m.get(), l, 0, s()));
+            it = mono_.emplace(l, std::move(m)).first;
+        }
+        PhantomCiphertext d = make(a.chain_index(), a.scale());
+        check(pha_multiply_rns_poly(h(), d.data(), a.data(), it->second.get(), l, 2, 1, s()));
+        return d;
+    }
+    // modraise_inplace (src/boot/Bootstrapper.cu:2814-2868): one-limb ciphertext -> top level, t = m + q0 * I
+    PhantomCiphertext mod_raise(const PhantomCiphertext &a) {
+        if (a.chain_index() != bottom()) throw std::invalid_argument("mod_raise expects a ciphertext at the last level");
+        PhantomCiphertext d = make(1, a.scale());
+        check(pha_mod_raise(h(), a.data(), d.data(), s()));
+        return d;
+    }
+};
+
+// =====================================================================================================
+// Linear maps as sparse sets of generalised diagonals; the special FFT as a product of such maps
+// =====================================================================================================
+inline DiagMap compose_diagonals(const DiagMap &outer, const DiagMap &inner, int S) {
+    // v1 * rot(v2 * rot(x, d2), d1) = v1 * rot(v2, d1) * rot(x, d1 + d2)
+    DiagMap out;
+    for (const auto &o : outer)
+        for (const auto &i : inner) {
+            const int d = (o.first + i.first) % S;
+            cvec &acc = out[d];
+            if (acc.empty()) acc.assign(S, 0.0);
+            for (int j = 0; j < S; j++) acc[j] += o.second[j] * i.second[(j + o.first) % S];
+        }
+    for (auto it = out.begin(); it != out.end();) {
+        double m = 0;
+        for (const auto &v : it->second) m = std::max(m, std::abs(v));
+        it = m > 1e-300 ? std::next(it) : out.erase(it);
+    }
+    return out;
+}
+
+// one radix-2 stage of the special FFT over the rotation group (the butterflies of src/fft.cu, twiddle
+// exp(2 pi i (5^j mod 4 len) / (4 len))): forward (u, v) -> (u + w v, u - w v); inverse (a, b) -> ((a + b)/2, (a - b) conj(w)/2)
+inline DiagMap special_fft_stage(int S, int length, bool inverse) {
+    const int lenh = length / 2, lenq = length * 4;
+    std::vector<std::complex<double>> tw(lenh);
+    long long p = 1;
+    const double kPi = 3.14159265358979323846;
+    for (int t = 0; t < lenh; t++) {
+        tw[t] = std::polar(1.0, 2.0 * kPi * static_cast<double>(p) / lenq);
+        p = p * 5 % lenq;
+    }
+    DiagMap out;
+    auto put = [&](int d, int j, std::complex<double> v) {
+        cvec &a = out[((d % S) + S) % S];
+        if (a.empty()) a.assign(S, 0.0);
+        a[j] += v;
+    };
+    for (int j = 0; j < S; j++) {
+        const int r = j % length;
+        const bool first = r < lenh;
+        const std::complex<double> w = tw[r % lenh];
+        if (!inverse) {
+            put(0, j, first ? 1.0 : -w);
+            if (first) put(lenh, j, w);
+            else put(S - lenh, j, 1.0);
+        } else {
+            put(0, j, first ? std::complex<double>(0.5) : -0.5 * std::conj(w));
+            if (first) put(lenh, j, 0.5);
+            else put(S - lenh, j, 0.5 * std::conj(w));
+        }
+    }
+    return out;
+}
+
+// the log2(S) stages merged into n_groups maps, in application order: forward len = 2, 4, .., S on bit-reversed input;
+// inverse len = S, .., 2 leaving bit-reversed output
+inline std::vector<DiagMap> special_fft_groups(int S, int n_groups, bool inverse) {
+    std::vector<int> lengths;
+    for (int l = 2; l <= S; l <<= 1) lengths.push_back(l);
+    if (inverse) std::reverse(lengths.begin(), lengths.end());
+    const int total = static_cast<int>(lengths.size());
+    n_groups = std::max(1, std::min(n_groups, total));
+    std::vector<DiagMap> groups;
+    int pos = 0;
+    for (int i = 0; i < n_groups; i++) {
+        const int cnt = total / n_groups + (i < total % n_groups ? 1 : 0);
+        DiagMap m;
+        m[0] = cvec(S, 1.0);
+        for (int k = pos; k < pos + cnt; k++) m = compose_diagonals(special_fft_stage(S, lengths[k], inverse), m, S);
+        pos += cnt;
+        if (!m.empty()) groups.push_back(std::move(m));
+    }
+    return groups;
+}
+
+// x -> sum_d v_d * rot(x, d) on S slots: baby-step / giant-step over the offsets that occur (multiples of one
+// stride), hoisted baby rotations, fused multiply-accumulate; one level
+class DiagonalTransform {
+    CKKSEvaluator *ev_;
+    int S_, stride_ = 1, n1_ = 1;
+    size_t level_;
+    DiagMap diagonals_;
+    std::map<int, std::vector<std::pair<int, PhantomPlaintext>>> terms_;  // giant g -> (baby b, plaintext)
+    std::vector<int> babies_;
+
+public:
+    DiagonalTransform(CKKSEvaluator *ev, DiagMap diagonals, int S, size_t level) : ev_(ev), S_(S), level_(level), diagonals_(std::move(diagonals)) {
+        int stride = S;
+        for (const auto &d : diagonals_)
+            if (d.first) stride = std::gcd(stride, d.first);
+        stride_ = stride;
+        const int m = S / stride;
+        const double cnt = std::max<double>(2.0, static_cast<double>(diagonals_.size()));
+        n1_ = std::max(1, 1 << static_cast<int>(std::ceil(std::log2(cnt) / 2.0)));
+        n1_ = std::min(n1_, m);
+        std::set<int> babies;
+        for (const auto &d : diagonals_) babies.insert((d.first / stride_) % n1_);
+        babies_.assign(babies.begin(), babies.end());
+    }
+    size_t level() const { return level_; }
+    std::vector<int> steps() const {
+        std::vector<int> out;
+        for (int b : babies_)
+            if (b) out.push_back(b * stride_);
+        std::set<int> giants;
+        for (const auto &d : diagonals_) giants.insert((d.first / stride_) / n1_);
+        for (int g : giants)
+            if (g) out.push_back(g * n1_ * stride_);
+        return out;
+    }
+    // encode the diagonals (rotated back by their giant step) at diag_scale
+    void encode(double diag_scale) {
+        terms_.clear();
+        for (const auto &d : diagonals_) {
+            const int k = d.first / stride_, g = k / n1_, b = k % n1_, shift = g * n1_ * stride_;
+            cvec rolled(S_);
+            for (int j = 0; j < S_; j++) rolled[j] = d.second[((j - shift) % S_ + S_) % S_];
+            terms_[g].emplace_back(b, ev_->encode(rolled, diag_scale, level_, static_cast<size_t>(S_)));
+        }
+    }
+    PhantomCiphertext apply(const PhantomCiphertext &in) {
+        PhantomCiphertext tmp;
+        const PhantomCiphertext &ct = ev_->at_level(in, level_, tmp);
+        std::vector<int> steps;
+        for (int b : babies_) steps.push_back(b * stride_);
+        std::vector<PhantomCiphertext> rot = ev_->rotate_many(ct, steps);
+        std::map<int, const PhantomCiphertext *> by_baby;
+        for (size_t i = 0; i < babies_.size(); i++) by_baby[babies_[i]] = &rot[i];
+        PhantomCiphertext total;
+        for (auto &gt : terms_) {
+            PhantomCiphertext inner;
+            for (auto &bp : gt.second) ev_->mul_plain_add(inner, *by_baby.at(bp.first), bp.second);
+            if (gt.first) inner = ev_->rotate(inner, gt.first * n1_ * stride_);
+            if (total.data() == nullptr)
+                total = std::move(inner);
+            else
+                ev_->add_inplace(total, inner);
+        }
+        return ev_->rescale(total);
+    }
+};
+
+// =====================================================================================================
+// Chebyshev series on [-1, 1] by baby-step / giant-step (Paterson-Stockmeyer) with exact target scales
+// =====================================================================================================
+class ChebyshevEvaluator {
+    CKKSEvaluator *ev_;
+    std::vector<double> c_;
+    int m_, l_;
+    std::map<int, PhantomCiphertext> T_;
+
+    struct Val {
+        enum Kind { NONE, CONST, CT } kind = NONE;
+        double c = 0;
+        PhantomCiphertext ct;
+    };
+    static void trim(std::vector<double> &c) {
+        while (!c.empty() && c.back() == 0.0) c.pop_back();
+    }
+    // T_{a+b} = 2 T_a T_b - T_{|a-b|}
+    PhantomCiphertext product(int a, int b) {
+        const PhantomCiphertext &x = T_.at(a), &y = T_.at(b);
+        const size_t lvl = std::max(x.chain_index(), y.chain_index());
+        PhantomCiphertext tx, ty;
+        PhantomCiphertext p = ev_->mul(ev_->at_level(x, lvl, tx), ev_->at_level(y, lvl, ty));
+        ev_->add_inplace(p, p);
+        p = ev_->rescale(p);
+        if (a == b) return ev_->add_const(p, -1.0);
+        return ev_->sub(p, ev_->to_level_scale(T_.at(std::abs(a - b)), p.chain_index(), p.scale()));
+    }
+    void powers(const PhantomCiphertext &w) {
+        T_.clear();
+        T_.emplace(1, w.clone(ev_->stream.get_stream()));
+        for (int j = 2; j < (1 << l_); j++) {  // babies T_2 .. T_{2^l - 1}
+            int a = 1;
+            while (2 * a <= j) a <<= 1;
+            T_.emplace(j, j == a ? product(j / 2, j / 2) : product(a, j - a));
+        }
+        for (int k = l_; k < m_; k++) {  // giants T_{2^l} .. T_{2^(m-1)}
+            const int hh = 1 << k;
+            if (!T_.count(hh)) T_.emplace(hh, product(hh / 2, hh / 2));
+        }
+    }
+    // sum_j c_j T_j, j < 2^l, landing exactly on (level, scale)
+    Val leaf(const std::vector<double> &c, size_t level, double scale) {
+        Val out;
+        const size_t lvl = level - 1;
+        const double ql = ev_->q_last(lvl);
+        PhantomCiphertext acc;
+        for (size_t j = 1; j < c.size(); j++) {
+            if (std::abs(c[j]) < 1e-300) continue;
+            PhantomCiphertext tmp;
+            const PhantomCiphertext &t = ev_->at_level(T_.at(static_cast<int>(j)), lvl, tmp);
+            ev_->mul_plain_add(acc, t, ev_->const_pt(c[j], scale * ql / t.scale(), lvl));
+        }
+        if (acc.data() == nullptr) {
+            if (std::abs(c[0]) >= 1e-300) out.kind = Val::CONST, out.c = c[0];
+            return out;
+        }
+        if (std::abs(c[0]) >= 1e-300) acc = ev_->add_const(acc, c[0]);
+        out.kind = Val::CT;
+        out.ct = ev_->rescale(acc);
+        return out;
+    }
+    Val eval(std::vector<double> c, int k, size_t level, double scale) {
+        trim(c);
+        if (c.empty()) return Val{};
+        const size_t nb = size_t(1) << l_;
+        if (k <= l_ || c.size() <= nb) {
+            if (c.size() > nb) c.resize(nb);
+            return leaf(c, level, scale);
+        }
+        const size_t hh = size_t(1) << (k - 1);
+        if (c.size() <= hh) return eval(std::move(c), k - 1, level, scale);
+        // p = q * T_h + r
+        std::vector<double> qc(c.size() - hh, 0.0), r(c.begin(), c.begin() + hh);
+        qc[0] = c[hh];
+        for (size_t j = hh + 1; j < c.size(); j++) {
+            qc[j - hh] = 2.0 * c[j];
+            r[2 * hh - j] -= c[j];
+        }
+        PhantomCiphertext tmp;
+        const PhantomCiphertext &Th = ev_->at_level(T_.at(static_cast<int>(hh)), level - 1, tmp);
+        const double qscale = scale * ev_->q_last(level - 1) / Th.scale();
+        Val qv = eval(std::move(qc), k - 1, level - 1, qscale);
+        Val rv = eval(std::move(r), k - 1, level, scale);
+        Val prod;
+        if (qv.kind == Val::CONST) {
+            prod.kind = Val::CT;
+            prod.ct = ev_->rescale(ev_->mul_const(Th, qv.c, qscale));
+        } else if (qv.kind == Val::CT) {
+            prod.kind = Val::CT;
+            prod.ct = ev_->rescale(ev_->mul(qv.ct, Th));
+        }
+        if (prod.kind == Val::NONE) return rv;
+        if (rv.kind == Val::NONE) return prod;
+        if (rv.kind == Val::CONST)
+            prod.ct = ev_->add_const(prod.ct, rv.c);
+        else
+            ev_->add_inplace(prod.ct, rv.ct);
+        return prod;
+    }
+
+public:
+    ChebyshevEvaluator() : ev_(nullptr), m_(1), l_(1) {}
+    ChebyshevEvaluator(CKKSEvaluator *ev, std::vector<double> coeffs, int baby_log = 2) : ev_(ev), c_(std::move(coeffs)) {
+        const double d = static_cast<double>(c_.size()) - 1.0;
+        m_ = std::max(1, static_cast<int>(std::ceil(std::log2(d + 1.0))));
+        l_ = std::min(baby_log, m_);
+    }
+    int depth() const { return m_ + 1; }
+    // Chebyshev interpolant of f at the degree + 1 Chebyshev points of the first kind
+    static std::vector<double> interpolate(const std::function<double(double)> &f, int degree) {
+        const int nn = degree + 1;
+        const double kPi = 3.14159265358979323846;
+        std::vector<double> fx(nn), c(nn);
+        for (int k = 0; k < nn; k++) fx[k] = f(std::cos(kPi * (k + 0.5) / nn));
+        for (int j = 0; j < nn; j++) {
+            double acc = 0;
+            for (int k = 0; k < nn; k++) acc += fx[k] * std::cos(kPi * j * (k + 0.5) / nn);
+            c[j] = acc * (j == 0 ? 1.0 : 2.0) / nn;
+        }
+        return c;
+    }
+    // p(w) at level w.level + depth(), scale exactly target_scale
+    PhantomCiphertext operator()(const PhantomCiphertext &w, double target_scale) {
+        powers(w);
+        Val v = eval(c_, m_, w.chain_index() + depth(), target_scale);
+        T_.clear();
+        if (v.kind != Val::CT) throw std::logic_error("the polynomial is constant");
+        return std::move(v.ct);
+    }
+};
+
+// =====================================================================================================
+// Bootstrapper
+// =====================================================================================================
+class Bootstrapper {
+public:
+    long loge, logn, n, logNh, Nh, L;
+    double initial_scale, final_scale;
+    long boundary_K, sin_cos_deg, scale_factor, inverse_deg;
+    CKKSEvaluator *ckks = nullptr;
+    std::vector<long> slot_vec;
+    int lt_levels = 3;        // groups per linear transform (the "_3" of the reference's API)
+    double evalmod_scale = 0;  // 0: the power of two nearest to the first EvalMod prime
+
+private:
+    ChebyshevEvaluator cheb_;
+    std::vector<DiagonalTransform> c2s_, s2c_;
+    size_t evalmod_level_ = 0, s2c_level_ = 0, out_level_ = 0;
+    double delta_ = 0, Kb_ = 0;
+    bool prepared_ = false, generated_ = false;
+
+    int groups() const { return std::max(1, std::min<int>(lt_levels, static_cast<int>(logn))); }
+    size_t slots() const { return size_t(1) << logn; }
+    void plan_levels() {
+        evalmod_level_ = 1 + groups();
+        s2c_level_ = evalmod_level_ + cheb_.depth() + scale_factor;
+        out_level_ = s2c_level_ + groups();
+        if (out_level_ > ckks->bottom()) throw std::invalid_argument("the modulus chain is too short for bootstrapping");
+        delta_ = evalmod_scale > 0 ? evalmod_scale : std::exp2(std::round(std::log2(ckks->q_last(evalmod_level_))));
+    }
+    void build_transforms() {
+        if (!c2s_.empty()) return;
+        const int S = static_cast<int>(slots());
+        size_t lvl = 1;
+        for (auto &g : special_fft_groups(S, groups(), true)) c2s_.emplace_back(ckks, std::move(g), S, lvl++);
+        lvl = s2c_level_;
+        for (auto &g : special_fft_groups(S, groups(), false)) s2c_.emplace_back(ckks, std::move(g), S, lvl++);
+    }
+    PhantomCiphertext eval_mod(const PhantomCiphertext &w) {
+        PhantomCiphertext c = cheb_(w, delta_);
+        for (long i = 0; i < scale_factor; i++) c = ckks->square_double_minus_one(c);
+        return c;
+    }
+
+public:
+    Bootstrapper(long _loge, long _logn, long _logNh, long _L, double _final_scale, long _boundary_K, long _sin_cos_deg,
+                 long _scale_factor, long _inverse_deg, CKKSEvaluator *_ckks)
+        : loge(_loge), logn(_logn), n(1L << _logn), logNh(_logNh), Nh(1L << _logNh), L(_L), initial_scale(_final_scale),
+          final_scale(_final_scale), boundary_K(_boundary_K), sin_cos_deg(_sin_cos_deg), scale_factor(_scale_factor),
+          inverse_deg(_inverse_deg), ckks(_ckks) {
+        if (logn < 1 || logn > logNh) throw std::invalid_argument("logn out of range");
+    }
+    void set_final_scale(double _final_scale) { final_scale = _final_scale; }
+    size_t levels_needed() const { return out_level_; }
+
+    // the approximate polynomial: Chebyshev interpolant of cos(2 pi (Kb w - 1/4) / 2^r) on [-1, 1], Kb = K + 1/2
+    void prepare_mod_polynomial() {
+        Kb_ = static_cast<double>(boundary_K) + 0.5;
+        const double Kb = Kb_, rr = std::exp2(static_cast<double>(scale_factor)), kPi = 3.14159265358979323846;
+        cheb_ = ChebyshevEvaluator(ckks, ChebyshevEvaluator::interpolate(
+                                             [=](double w) { return std::cos(2.0 * kPi * (Kb * w - 0.25) / rr); },
+                                             static_cast<int>(sin_cos_deg)));
+        plan_levels();
+        prepared_ = true;
+    }
+    // rotation steps of SubSum and of the two linear transforms
+    void addLeftRotKeys_Linear_to_vector_3(std::vector<int> &gal_steps_vector) {
+        if (!prepared_) prepare_mod_polynomial();
+        build_transforms();
+        std::set<int> have(gal_steps_vector.begin(), gal_steps_vector.end());
+        auto add = [&](int st) {
+            if (have.insert(st).second) gal_steps_vector.push_back(st);
+        };
+        for (auto &t : c2s_)
+            for (int st : t.steps()) add(st);
+        for (auto &t : s2c_)
+            for (int st : t.steps()) add(st);
+        for (long k = n; k < Nh; k <<= 1) add(static_cast<int>(k));
+    }
+    // encode the diagonals of both transforms at the scales that keep the bookkeeping exact
+    void generate_LT_coefficient_3() {
+        if (!prepared_) prepare_mod_polynomial();
+        build_transforms();
+        const double q0 = ckks->q(0), kPi = 3.14159265358979323846;
+        const double g = static_cast<double>(Nh) / static_cast<double>(n);
+        const double norm = 1.0 / (g * Kb_ * 2.0);
+        // CoeffToSlot: intermediate results keep the re-declared scale q0, the last group lands on the EvalMod scale
+        const size_t n_c2s = c2s_.size(), n_s2c = s2c_.size();
+        const double c2s_cst = std::pow(norm, 1.0 / n_c2s);
+        rebuild(c2s_, true, c2s_cst, [&](size_t i, size_t lvl) { return ckks->q_last(lvl) * (i + 1 == n_c2s ? delta_ / q0 : 1.0); });
+        // EvalMod output scale: delta after the polynomial, squared and rescaled by every double angle
+        double sv = delta_;
+        size_t lvl = evalmod_level_ + cheb_.depth();
+        for (long i = 0; i < scale_factor; i++, lvl++) sv = sv * sv / ckks->q_last(lvl);
+        const double s2c_cst = std::pow((q0 / final_scale) / (2.0 * kPi), 1.0 / n_s2c);
+        rebuild(s2c_, false, s2c_cst, [&](size_t i, size_t l2) { return ckks->q_last(l2) * (i == 0 ? final_scale / sv : 1.0); });
+        generated_ = true;
+    }
+
+private:
+    // re-create the transforms with every diagonal multiplied by `cst`, then encode
+    void rebuild(std::vector<DiagonalTransform> &ts, bool inverse, double cst, const std::function<double(size_t, size_t)> &scale_of) {
+        const int S = static_cast<int>(slots());
+        std::vector<DiagMap> maps = special_fft_groups(S, groups(), inverse);
+        const size_t first = ts.front().level();
+        ts.clear();
+        for (size_t i = 0; i < maps.size(); i++) {
+            for (auto &d : maps[i])
+                for (auto &v : d.second) v *= cst;
+            ts.emplace_back(ckks, std::move(maps[i]), S, first + i);
+            ts.back().encode(scale_of(i, first + i));
+        }
+    }
+
+public:
+    void modraise_inplace(PhantomCiphertext &cipher) {
+        PhantomCiphertext t = ckks->mod_raise(cipher);
+        cipher = std::move(t);
+    }
+    // sparse (n < Nh: SubSum first) and full (n == Nh) packings take the same path
+    void bootstrap_3(PhantomCiphertext &rtncipher, PhantomCiphertext &cipher) {
+        if (!generated_) throw std::logic_error("generate_LT_coefficient_3() has not been called");
+        if (std::abs(cipher.scale() / final_scale - 1.0) > 0.01) throw std::invalid_argument("the bootstrapper was set up for ciphertexts of scale final_scale");
+        const double in_scale = cipher.scale(), q0 = ckks->q(0);
+        PhantomCiphertext tmp;
+        PhantomCiphertext t = ckks->mod_raise(ckks->at_level(cipher, ckks->bottom(), tmp));
+        t.set_scale(q0);  // src/boot/Bootstrapper.cu:2867-2868
+        for (long k = n; k < Nh; k <<= 1) {  // SubSum onto the n-slot subring (:2870-2876)
+            PhantomCiphertext r = ckks->rotate(t, static_cast<int>(k));
+            ckks->add_inplace(t, r);
+        }
+        for (auto &lt : c2s_) t = lt.apply(t);  // (x_k + i x_{k+n}) / (2 Kb), bit-reversed slot order
+        PhantomCiphertext cj = ckks->conj(t);
+        PhantomCiphertext re = ckks->add(t, cj);
+        PhantomCiphertext im = ckks->neg(ckks->mul_i(ckks->sub(t, cj)));
+        PhantomCiphertext v = eval_mod(re);  // 2 pi m / q0 on both parts
+        PhantomCiphertext vi = ckks->mul_i(eval_mod(im));
+        ckks->add_inplace(v, vi);
+        for (auto &lt : s2c_) v = lt.apply(v);
+        v.set_scale(v.scale() * in_scale / final_scale);  // src/boot/Bootstrapper.cu:2933 (a ratio of ~1)
+        rtncipher = std::move(v);
+    }
+    void bootstrap_sparse_3(PhantomCiphertext &rtncipher, PhantomCiphertext &cipher) { bootstrap_3(rtncipher, cipher); }
+    void bootstrap_full_3(PhantomCiphertext &rtncipher, PhantomCiphertext &cipher) { bootstrap_3(rtncipher, cipher); }
+    void bootstrap_inplace_3(PhantomCiphertext &cipher) {
+        PhantomCiphertext rtn;
+        bootstrap_3(rtn, cipher);
+        cipher = std::move(rtn);
+    }
+};
+
+}  // namespace phantom

@@ -20,6 +20,34 @@ def test_header_only_layer_is_self_contained():
     assert "oracle" not in hdr
 
 
+def test_bootstrap_header_mirrors_the_reference_api():
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "phantom-fhe_amd", "host", "phantom_boot.hpp")).read()
+    for name in ("class CKKSEvaluator", "class Bootstrapper", "prepare_mod_polynomial", "addLeftRotKeys_Linear_to_vector_3",
+                 "generate_LT_coefficient_3", "bootstrap_3", "bootstrap_sparse_3", "bootstrap_full_3", "bootstrap_inplace_3",
+                 "modraise_inplace", "slot_vec", "create_galois_keys_from_steps"):
+        assert name in hdr
+    assert "oracle" not in hdr
+
+
+@pytest.mark.gpu
+def test_cpp_bootstrapper(gpu):
+    """The flow of the reference's examples/bootstrapping.cu on the C++ host layer: full slots (2048 of N = 2^12)
+    and a sparse packing.  tests/bootstrapping_test.cu asks for a mean error around 1e-3."""
+    exe = os.path.join(os.path.dirname(__file__), "cpp", "bootstrap_test")
+    assert os.path.exists(exe), "tests/cpp/bootstrap_test not built (run __graft_entry__.build())"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    res = {}
+    for line in out.stdout.splitlines():
+        if line.startswith("{"):
+            res.update(json.loads(line))
+    full, sparse = res["full_slots"], res["sparse_128"]
+    assert full["slots"] == 2048 and full["return_limbs"] == 3 and full["return_level"] == full["levels_needed"] == 16
+    assert full["input_err"] < 1e-9 and full["max_err"] < 2e-5 and full["square_err"] < 4e-5      # delta = 2^50
+    assert sparse["slots"] == 128 and sparse["return_limbs"] == 3
+    assert sparse["max_err"] < 1e-3 and sparse["mean_err"] < 2e-4 and sparse["square_err"] < 2e-3  # delta = 2^40
+
+
 @pytest.mark.gpu
 def test_cpp_host_layer_against_oracle(gpu, orc):
     assert os.path.exists(BIN), "tests/cpp/host_mirror_test not built (run __graft_entry__.build())"
