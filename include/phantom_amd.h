@@ -220,6 +220,17 @@ int pha_gen_secretkey(pha_context *ctx, uint64_t seed, uint64_t *sk, pha_stream_
 /* encrypt_zero_symmetric (src/secretkey.cu:207-263, NTT form): ct[2][l][N] = (-(a*s+e), a) */
 int pha_encrypt_zero_symmetric(pha_context *ctx, const uint64_t *sk, size_t chain_index, uint64_t seed_a,
                                uint64_t seed_e, uint64_t *ct, pha_stream_t stream);
+/* PhantomSecretKey::gen_publickey (src/secretkey.cu:437-452): pk[2][size_QP][N] = an encryption of zero at the key
+ * level; seeded (outputs 0, 1 of the stream at `seed` drive a and e) */
+int pha_gen_publickey(pha_context *ctx, const uint64_t *sk, uint64_t seed, uint64_t *pk, pha_stream_t stream);
+/* PhantomPublicKey::encrypt_zero_asymmetric_internal / encrypt_asymmetric (src/secretkey.cu:15-164):
+ * cx_i = pk_i * u + e_i at the key level (u ternary), divided by P onto the first data level (moddown), limbs
+ * dropped for chain_index > 1; ct[2][l][N], plain[l][N] in NTT form.  e_0 and e_1 use distinct seeds here (the
+ * reference draws both from one seed). */
+int pha_encrypt_zero_asymmetric(pha_context *ctx, const uint64_t *pk, size_t chain_index, uint64_t seed, uint64_t *ct,
+                                pha_stream_t stream);
+int pha_encrypt_asymmetric(pha_context *ctx, const uint64_t *pk, const uint64_t *plain, size_t chain_index, uint64_t seed,
+                           uint64_t *ct, pha_stream_t stream);
 /* encrypt_symmetric (src/secretkey.cu:548-582): c0 += plain, plain[l][N] in NTT form */
 int pha_encrypt_symmetric(pha_context *ctx, const uint64_t *sk, const uint64_t *plain, size_t chain_index,
                           uint64_t seed_a, uint64_t seed_e, uint64_t *ct, pha_stream_t stream);

@@ -78,6 +78,9 @@ def lib():
             "orc_gen_secretkey": (None, [_vp, _u64, _u64p]),
             "orc_encrypt_zero_symmetric": (None, [_vp, _u64p, _sz, _u64, _u64, _u64p]),
             "orc_encrypt_symmetric": (None, [_vp, _u64p, _u64p, _sz, _u64, _u64, _u64p]),
+            "orc_gen_publickey": (None, [_vp, _u64p, _u64, _u64p]),
+            "orc_encrypt_zero_asymmetric": (None, [_vp, _u64p, _sz, _u64, _u64p]),
+            "orc_encrypt_asymmetric": (None, [_vp, _u64p, _u64p, _sz, _u64, _u64p]),
             "orc_ckks_decrypt": (None, [_vp, _u64p, _u64p, _sz, _sz, _u64p]),
             "orc_generate_one_kswitch_key": (None, [_vp, _u64p, _u64p, _u64, ctypes.POINTER(_u64p)]),
             "orc_gen_relinkey": (None, [_vp, _u64p, _u64, ctypes.POINTER(_u64p)]),
@@ -285,6 +288,21 @@ class Oracle:
     def encrypt_symmetric(self, sk, plain, chain_index, seed_a, seed_e):
         ct = np.zeros((2, self.level_limbs(chain_index), self.n), dtype=np.uint64)
         lib().orc_encrypt_symmetric(self._h, p(sk), p(np.ascontiguousarray(plain)), chain_index, seed_a, seed_e, p(ct))
+        return ct
+
+    def gen_publickey(self, sk, seed):
+        pk = np.zeros((2, self.size_QP, self.n), dtype=np.uint64)
+        lib().orc_gen_publickey(self._h, p(sk), seed, p(pk))
+        return pk
+
+    def encrypt_zero_asymmetric(self, pk, chain_index, seed):
+        ct = np.zeros((2, self.level_limbs(chain_index), self.n), dtype=np.uint64)
+        lib().orc_encrypt_zero_asymmetric(self._h, p(np.ascontiguousarray(pk)), chain_index, seed, p(ct))
+        return ct
+
+    def encrypt_asymmetric(self, pk, plain, chain_index, seed):
+        ct = np.zeros((2, self.level_limbs(chain_index), self.n), dtype=np.uint64)
+        lib().orc_encrypt_asymmetric(self._h, p(np.ascontiguousarray(pk)), p(np.ascontiguousarray(plain)), chain_index, seed, p(ct))
         return ct
 
     def ckks_decrypt(self, sk, ct, chain_index):

@@ -804,6 +804,48 @@ void orc_encrypt_symmetric(const orc_ctx *c, const uint64_t *sk, const uint64_t 
         for (size_t k = 0; k < n; k++) ct[l * n + k] = addmod(ct[l * n + k], plain[l * n + k], c->q[l]);
 }
 
+/* PhantomSecretKey::gen_publickey (src/secretkey.cu:437-452): an encryption of zero at the key level,
+ * pk[2][size_QP][n]; the two seeds are outputs 0 and 1 of the stream at `seed` */
+void orc_gen_publickey(const orc_ctx *c, const uint64_t *sk, uint64_t seed, uint64_t *pk) {
+    orc_encrypt_zero_symmetric(c, sk, 0, rnd_at(seed, 0), rnd_at(seed, 1), pk);
+}
+
+/* PhantomPublicKey::encrypt_zero_asymmetric_internal (src/secretkey.cu:15-131): at the key level
+ * cx_i = pk_i * u + e_i with u ternary and e_0, e_1 from the error distribution (seeds: outputs 0, 1, 2 of the
+ * stream at `seed`; the reference reuses one seed for e_0 and e_1), then each poly is divided by P
+ * (moddown) onto the first data level; lower levels drop limbs (CKKS mod_switch_to_next). */
+void orc_encrypt_zero_asymmetric(const orc_ctx *c, const uint64_t *pk, size_t chain_index, uint64_t seed, uint64_t *ct) {
+    const size_t n = c->n, QP = c->size_QP, Q = c->size_QP - c->size_P, limbs = level_limbs(c, chain_index);
+    uint64_t *u = (uint64_t *)malloc(QP * n * sizeof(uint64_t));
+    uint64_t *cx = (uint64_t *)malloc(QP * n * sizeof(uint64_t));
+    uint64_t *top = (uint64_t *)malloc(Q * n * sizeof(uint64_t));
+    orc_sample_ternary(c, u, QP, NULL, rnd_at(seed, 0));
+    for (size_t l = 0; l < QP; l++) orc_ntt_fwd(c, u + l * n, l);
+    for (int i = 0; i < 2; i++) {
+        orc_sample_error(c, cx, QP, NULL, rnd_at(seed, 1 + (uint64_t)i));
+        for (size_t l = 0; l < QP; l++) {
+            orc_ntt_fwd(c, cx + l * n, l);
+            const uint64_t q = c->q[l];
+            for (size_t k = 0; k < n; k++)
+                cx[l * n + k] = addmod(mulmod(u[l * n + k], pk[((size_t)i * QP + l) * n + k], q), cx[l * n + k], q);
+        }
+        orc_moddown_from_ntt(c, Q, top, cx);
+        memcpy(ct + (size_t)i * limbs * n, top, limbs * n * sizeof(uint64_t));
+    }
+    free(u);
+    free(cx);
+    free(top);
+}
+
+/* PhantomPublicKey::encrypt_asymmetric (src/secretkey.cu:133-164): c0 += plain */
+void orc_encrypt_asymmetric(const orc_ctx *c, const uint64_t *pk, const uint64_t *plain, size_t chain_index, uint64_t seed,
+                            uint64_t *ct) {
+    const size_t limbs = level_limbs(c, chain_index), n = c->n;
+    orc_encrypt_zero_asymmetric(c, pk, chain_index, seed, ct);
+    for (size_t l = 0; l < limbs; l++)
+        for (size_t k = 0; k < n; k++) ct[l * n + k] = addmod(ct[l * n + k], plain[l * n + k], c->q[l]);
+}
+
 /* src/secretkey.cu:584-624: plain = c0 + sum_i c_i * s^i (NTT form) */
 void orc_ckks_decrypt(const orc_ctx *c, const uint64_t *sk, const uint64_t *ct, size_t cipher_size, size_t chain_index,
                       uint64_t *plain) {

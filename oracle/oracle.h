@@ -97,6 +97,10 @@ void orc_sample_uniform(const orc_ctx *c, uint64_t *out, size_t limbs, const siz
 void orc_gen_secretkey(const orc_ctx *c, uint64_t seed, uint64_t *sk);
 void orc_encrypt_zero_symmetric(const orc_ctx *c, const uint64_t *sk, size_t chain_index, uint64_t seed_a,
                                 uint64_t seed_e, uint64_t *ct);
+void orc_gen_publickey(const orc_ctx *c, const uint64_t *sk, uint64_t seed, uint64_t *pk);
+void orc_encrypt_zero_asymmetric(const orc_ctx *c, const uint64_t *pk, size_t chain_index, uint64_t seed, uint64_t *ct);
+void orc_encrypt_asymmetric(const orc_ctx *c, const uint64_t *pk, const uint64_t *plain, size_t chain_index, uint64_t seed,
+                            uint64_t *ct);
 void orc_encrypt_symmetric(const orc_ctx *c, const uint64_t *sk, const uint64_t *plain, size_t chain_index,
                            uint64_t seed_a, uint64_t seed_e, uint64_t *ct);
 void orc_ckks_decrypt(const orc_ctx *c, const uint64_t *sk, const uint64_t *ct, size_t cipher_size, size_t chain_index,

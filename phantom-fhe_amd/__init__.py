@@ -77,6 +77,9 @@ SIGNATURES = {
     "pha_gen_secretkey": (_int, [_vp, _u64, _vp, _vp]),
     "pha_encrypt_zero_symmetric": (_int, [_vp, _vp, _sz, _u64, _u64, _vp, _vp]),
     "pha_encrypt_symmetric": (_int, [_vp, _vp, _vp, _sz, _u64, _u64, _vp, _vp]),
+    "pha_gen_publickey": (_int, [_vp, _vp, _u64, _vp, _vp]),
+    "pha_encrypt_zero_asymmetric": (_int, [_vp, _vp, _sz, _u64, _vp, _vp]),
+    "pha_encrypt_asymmetric": (_int, [_vp, _vp, _vp, _sz, _u64, _vp, _vp]),
     "pha_ckks_decrypt": (_int, [_vp, _vp, _vp, _sz, _sz, _vp, _vp]),
     "pha_generate_one_kswitch_key": (_int, [_vp, _vp, _vp, _u64, ctypes.POINTER(_vp), _vp]),
     "pha_gen_relinkey": (_int, [_vp, _vp, _u64, ctypes.POINTER(_vp), _vp]),
@@ -417,6 +420,23 @@ class PhantomContext:
         ct = self._empty(2, self.level_limbs(chain_index))
         _check(lib().pha_encrypt_symmetric(self._h, _ptr(sk), _ptr(plain), chain_index, seed_a, seed_e, _ptr(ct),
                                            _stream()))
+        return ct
+
+    def gen_publickey(self, sk, seed):
+        """PhantomSecretKey::gen_publickey (src/secretkey.cu:437-452): [2][size_QP][N]"""
+        pk = self._empty(2, self.size_QP)
+        _check(lib().pha_gen_publickey(self._h, _ptr(sk), seed, _ptr(pk), _stream()))
+        return pk
+
+    def encrypt_zero_asymmetric(self, pk, chain_index, seed):
+        ct = self._empty(2, self.level_limbs(chain_index))
+        _check(lib().pha_encrypt_zero_asymmetric(self._h, _ptr(pk), chain_index, seed, _ptr(ct), _stream()))
+        return ct
+
+    def encrypt_asymmetric(self, pk, plain, chain_index, seed):
+        """PhantomPublicKey::encrypt_asymmetric (src/secretkey.cu:133-164)"""
+        ct = self._empty(2, self.level_limbs(chain_index))
+        _check(lib().pha_encrypt_asymmetric(self._h, _ptr(pk), _ptr(plain), chain_index, seed, _ptr(ct), _stream()))
         return ct
 
     def ckks_decrypt(self, sk, ct, chain_index):

@@ -1369,6 +1369,51 @@ int pha_encrypt_symmetric(pha_context *ctx, const uint64_t *sk, const uint64_t *
     return launch_ew(ctx, EW_ADD, ct, ct, plain, nullptr, nullptr, 0, limbs, as_stream(stream));
 }
 
+int pha_gen_publickey(pha_context *ctx, const uint64_t *sk, uint64_t seed, uint64_t *pk, pha_stream_t stream) {
+    REQUIRE_CTX(sk && pk);
+    return do_encrypt_zero(ctx, sk, 0, host_rnd_at(seed, 0), host_rnd_at(seed, 1), pk, as_stream(stream));
+}
+
+int pha_encrypt_zero_asymmetric(pha_context *ctx, const uint64_t *pk, size_t chain_index, uint64_t seed, uint64_t *ct,
+                                pha_stream_t stream) {
+    REQUIRE_CTX(pk && ct);
+    if (chain_index == 0) return fail(PHA_ERR_INVALID_ARGUMENT, "asymmetric encryption targets a data level (chain_index >= 1)");
+    if (ctx->size_P == 0) return fail(PHA_ERR_LOGIC, "asymmetric encryption needs a special modulus");
+    size_t limbs;
+    PHA_TRY(level_limbs(ctx, chain_index, &limbs));
+    hipStream_t st = as_stream(stream);
+    const size_t n = ctx->n, QP = ctx->size_QP, Q = ctx->size_Q;
+    LevelTool *lt;
+    PHA_TRY(get_level(ctx, 1, &lt));
+    // workspace: u[QP] | cx[2][QP] | delta[2][Q] | top[2][Q]
+    uint64_t *ws;
+    PHA_TRY(ensure_workspace(ctx, (3 * QP + 4 * Q) * n, &ws));
+    uint64_t *u = ws, *cx = u + QP * n, *delta = cx + 2 * QP * n, *top = delta + 2 * Q * n;
+    NttRange r;
+    PHA_TRY(make_range(ctx, QP, 0, 0, 0, 0, 0, r));
+    PHA_TRY(launch_sample(ctx, SAMPLE_TERNARY, u, QP, host_rnd_at(seed, 0), st));
+    PHA_TRY(ntt_forward(ctx, u, 1, 0, r, EPI_NONE, Epilogue{}, st));
+    for (size_t i = 0; i < 2; i++) PHA_TRY(launch_sample(ctx, SAMPLE_ERROR, cx + i * QP * n, QP, host_rnd_at(seed, 1 + i), st));
+    PHA_TRY(ntt_forward(ctx, cx, 2, QP * n, r, EPI_NONE, Epilogue{}, st));
+    for (size_t i = 0; i < 2; i++)   // cx_i = u * pk_i + e_i
+        PHA_TRY(launch_ew(ctx, EW_MUL_ADD, cx + i * QP * n, u, pk + i * QP * n, cx + i * QP * n, nullptr, 0, QP, st));
+    uint64_t *dst = limbs == Q ? ct : top;
+    PHA_TRY(do_moddown(ctx, lt, dst, cx, delta, nullptr, 2, st));
+    if (limbs != Q)  // lower levels: drop limbs (CKKS mod_switch_to_next)
+        HIP_TRY(hipMemcpy2DAsync(ct, limbs * n * sizeof(uint64_t), top, Q * n * sizeof(uint64_t), limbs * n * sizeof(uint64_t), 2,
+                                 hipMemcpyDeviceToDevice, st));
+    return PHA_OK;
+}
+
+int pha_encrypt_asymmetric(pha_context *ctx, const uint64_t *pk, const uint64_t *plain, size_t chain_index, uint64_t seed,
+                           uint64_t *ct, pha_stream_t stream) {
+    REQUIRE_CTX(pk && plain && ct);
+    PHA_TRY(pha_encrypt_zero_asymmetric(ctx, pk, chain_index, seed, ct, stream));
+    size_t limbs;
+    PHA_TRY(level_limbs(ctx, chain_index, &limbs));
+    return launch_ew(ctx, EW_ADD, ct, ct, plain, nullptr, nullptr, 0, limbs, as_stream(stream));
+}
+
 int pha_ckks_decrypt(pha_context *ctx, const uint64_t *sk, const uint64_t *ct, size_t cipher_size, size_t chain_index,
                      uint64_t *plain, pha_stream_t stream) {
     REQUIRE_CTX(sk && ct && plain);

@@ -187,6 +187,20 @@ int main() {
             double err = 0;
             for (size_t i = 0; i < n / 2; i++) err = std::max(err, std::abs(out[i] - (z1[i] + z2[i]) * z1[i]));
             printf("{\"encoder_pipeline_err\": %.3e}\n", err);
+            // public-key encryption (examples/*.cu: secret_key.gen_publickey + public_key.encrypt_asymmetric)
+            PhantomPublicKey pk = sk.gen_publickey(context, sw);
+            PhantomCiphertext ca, cb;
+            pk.encrypt_asymmetric(context, p1, ca, sw);
+            pk.encrypt_asymmetric(context, p1, cb, sw);
+            sk.decrypt(context, ca, dec, sw);
+            enc.decode(context, dec, out, sw);
+            double aerr = 0;
+            for (size_t i = 0; i < n / 2; i++) aerr = std::max(aerr, std::abs(out[i] - z1[i]));
+            std::vector<uint64_t> ha = download(ca), hb = download(cb);
+            size_t differ = 0;
+            for (size_t i = 0; i < ha.size(); i++) differ += ha[i] != hb[i];
+            printf("{\"asymmetric_err\": %.3e, \"asymmetric_fresh_randomness\": %.3f, \"asymmetric_limbs\": %zu}\n", aerr,
+                   (double)differ / (double)ha.size(), ca.coeff_modulus_size());
         }
 
         // error behaviour of the reference

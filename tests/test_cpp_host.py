@@ -15,7 +15,8 @@ def test_header_only_layer_is_self_contained():
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "phantom-fhe_amd", "host", "phantom_amd.hpp")).read()
     for name in ("multiply_inplace", "relinearize_inplace", "rescale_to_next", "rotate_inplace", "apply_galois_inplace",
                  "class PhantomContext", "class PhantomCiphertext", "class PhantomRelinKey", "class PhantomGaloisKey",
-                 "class PhantomSecretKey", "class PhantomPlaintext", "encrypt_symmetric", "gen_relinkey"):
+                 "class PhantomSecretKey", "class PhantomPlaintext", "encrypt_symmetric", "gen_relinkey",
+                 "class PhantomPublicKey", "gen_publickey", "encrypt_asymmetric"):
         assert name in hdr
     assert "oracle" not in hdr
 
@@ -111,3 +112,6 @@ def test_cpp_host_layer_against_oracle(gpu, orc):
     assert res["real_keys_rel_err"] < 1e-3 and res["real_keys_rest"] < 1e-3
     assert res["gen_twice_throws"] == 1
     assert res["encoder_pipeline_err"] < 1e-4
+    # public-key encryption: decrypts to the message, two encryptions of one plaintext differ.  Scale 2^30; the
+    # division by P is the reference's uncentred moddown, whose +1/2 mean per coefficient lands on slot 0 (9e-5)
+    assert res["asymmetric_err"] < 1e-3 and res["asymmetric_fresh_randomness"] > 0.99 and res["asymmetric_limbs"] == 4

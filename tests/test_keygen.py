@@ -79,6 +79,50 @@ def test_oracle_keys_decrypt(orc, chain_id):
     assert max(abs(a - b) for a, b in zip(h.decrypt(rot), h.galois_coeffs(p1, elt))) < DELTA * 1e-4
 
 
+@pytest.mark.parametrize("chain_id", [0, 1])
+def test_oracle_public_key_encryption_decrypts(orc, chain_id):
+    """PhantomPublicKey::encrypt_asymmetric (src/secretkey.cu:15-164): pk * u + e at the key level, divided by P.
+    The decryption error is the rounding of that division times (1 + s): far below one centred-binomial draw times N."""
+    mods, o = _setup(orc, CHAINS[chain_id])
+    sk = o.gen_secretkey(11)
+    h = _harness(o, sk)
+    pk = o.gen_publickey(sk, 61)
+    assert (pk == o.encrypt_zero_symmetric(sk, 0, orc.rnd_at(61, 0), orc.rnd_at(61, 1))).all()
+    p1, _ = _messages(5)
+    for chain_index in (1, 2):
+        limbs = o.level_limbs(chain_index)
+        ct = o.encrypt_asymmetric(pk, h.to_ntt(p1, range(limbs)), chain_index, 71)
+        assert ct.shape == (2, limbs, N)
+        dec = h.crt_compose(np.stack([o.ntt_inv(l, i) for i, l in enumerate(o.ckks_decrypt(sk, ct, chain_index))]), range(limbs))
+        assert max(abs(a - b) for a, b in zip(dec, p1)) <= N          # measured: a few hundred
+    z = o.encrypt_zero_asymmetric(pk, 1, 72)
+    assert (z != o.encrypt_zero_asymmetric(pk, 1, 73)).mean() > 0.99
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chain_id", [0, 1])
+def test_gpu_public_key_encryption_matches_oracle(gpu, pha, orc, chain_id):
+    mods, o = _setup(orc, CHAINS[chain_id])
+    ctx = pha.PhantomContext(LOG_N, mods, o.size_P)
+    sk_h, sk = o.gen_secretkey(11), ctx.gen_secretkey(11)
+    pk_h, pk = o.gen_publickey(sk_h, 61), ctx.gen_publickey(sk, 61)
+    assert (pha.to_host(pk) == pk_h).all()
+    h = _harness(o, sk_h)
+    p1, _ = _messages(5)
+    for chain_index in (1, 3):
+        limbs = o.level_limbs(chain_index)
+        assert (pha.to_host(ctx.encrypt_zero_asymmetric(pk, chain_index, 72)) == o.encrypt_zero_asymmetric(pk_h, chain_index, 72)).all()
+        pl = h.to_ntt(p1, range(limbs))
+        ct = ctx.encrypt_asymmetric(pk, pha.to_device(pl), chain_index, 71)
+        assert (pha.to_host(ct) == o.encrypt_asymmetric(pk_h, pl, chain_index, 71)).all()
+        plain = pha.to_host(ctx.ckks_decrypt(sk, ct, chain_index))
+        dec = h.crt_compose(np.stack([o.ntt_inv(plain[i], i) for i in range(limbs)]), range(limbs))
+        assert max(abs(a - b) for a, b in zip(dec, p1)) <= N
+    with pytest.raises(pha.PhantomError):
+        ctx.encrypt_zero_asymmetric(pk, 0, 1)
+    ctx.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("chain_id", [0, 1])
 def test_gpu_keygen_matches_oracle_and_decrypts(gpu, pha, orc, chain_id):
