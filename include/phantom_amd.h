@@ -293,6 +293,23 @@ int pha_rotate_hoisted(pha_context *ctx, size_t chain_index, const uint64_t *ct,
                        const uint32_t *galois_elts_host, const uint64_t *const *const *evks_host,
                        uint64_t *const *out_host, pha_stream_t stream);
 
+/* Plaintext over Q_l u P ([size_Ql + size_P][N], NTT form): pha_ckks_encode with the special primes appended, the
+ * operand format of pha_linear_transform_double_hoisted.  No counterpart in the reference. */
+int pha_ckks_encode_qp(pha_context *ctx, const double *values_host, size_t values_size, size_t sparse_slots,
+                       size_t chain_index, double scale, uint64_t *plain, pha_stream_t stream);
+/* Double-hoisted baby-step / giant-step linear transform, the inner loop of the bootstrapper's CoeffToSlot /
+ * SlotToCoeff (the reference's bsgs_linear_transform_hoisting family, src/boot/Bootstrapper.cu:1988-2127, shares the
+ * modup only; this also keeps the rotated ciphertexts over Q_l u P so that there are n_giant + 1 moddowns instead
+ * of n_baby + n_giant):  out[2][l][N] = sum_g rot_{G_g}( sum_b plains[g * n_baby + b] * rot_{B_b}(ct) ).
+ * Galois element 1 = no rotation (its key entry may be NULL); plains entries are device pointers to
+ * pha_ckks_encode_qp plaintexts or NULL for an absent diagonal; element / key / plaintext tables are HOST arrays.
+ * The result differs from the step-by-step evaluation by the rounding of the moddowns only. */
+int pha_linear_transform_double_hoisted(pha_context *ctx, size_t chain_index, const uint64_t *ct, size_t n_baby,
+                                        const uint32_t *baby_elts_host, const uint64_t *const *const *baby_evks_host,
+                                        size_t n_giant, const uint32_t *giant_elts_host,
+                                        const uint64_t *const *const *giant_evks_host, const uint64_t *const *plains_host,
+                                        uint64_t *out, pha_stream_t stream);
+
 /* ---- bootstrapping primitives -----------------------------------------------
  * Bootstrapper::modraise_inplace (src/boot/Bootstrapper.cu:2801-2861): src[2][1][N], a ciphertext at
  * the lowest level (one limb, NTT form) -> dst[2][size_Q][N] at the top level (chain_index 1),

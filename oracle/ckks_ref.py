@@ -238,3 +238,59 @@ def decode_ref(coeffs, scale, n, sparse_slots):
     gap = n // (2 * s)
     u = np.array([complex(coeffs[k * gap] / scale, coeffs[(k + s) * gap] / scale) for k in range(s)])
     return _slot_matrix(s) @ u
+
+
+# ---- double-hoisted linear transform, restated from the oracle's primitives ------------------------
+def linear_transform_double_hoisted_ref(o, size_ql, ct, baby_elts, baby_keys, giant_elts, giant_keys, plains):
+    """out = sum_g rot_G( sum_b plains[g][b] * rot_B(ct) ) evaluated as include/phantom_amd.h describes
+    pha_linear_transform_double_hoisted: rotated ciphertexts stay over Q_l u P (P * pi(c0) lifted onto the Q_l limbs),
+    one moddown per giant step and one at the end.  ct [2][size_ql][n]; plains[g][b] [size_ql + size_P][n] or None;
+    keys are lists of beta arrays [2][size_QP][n]; Galois element 1 = no rotation."""
+    n, size_p, size_q = o.n, o.size_P, o.size_Q
+    qlp = size_ql + size_p
+    mods = [int(o.moduli[j]) for j in range(size_ql)] + [int(o.moduli[size_q + i]) for i in range(size_p)]
+    big_p = o.level_constants(size_ql)["bigP_mod_q"]
+
+    def lift(poly, elt):
+        src = poly if elt == 1 else o.apply_galois_ntt(np.ascontiguousarray(poly), elt)
+        out = np.zeros((qlp, n), dtype=np.uint64)
+        for j in range(size_ql):
+            out[j] = _mulmod_vec(src[j], np.full(n, int(big_p[j]), dtype=np.uint64), mods[j])
+        return out
+
+    def addmod(a, b):
+        out = np.zeros_like(a)
+        for j in range(qlp):
+            v = a[..., j, :].astype(object) + b[..., j, :].astype(object)
+            out[..., j, :] = np.array(v % mods[j], dtype=np.uint64)
+        return out
+
+    def rotate_qp(src, elt, key):
+        if elt == 1:
+            return np.stack([lift(src[0], 1), lift(src[1], 1)])
+        t = o.modup(size_ql, np.ascontiguousarray(src[1]))
+        tp = np.stack([o.apply_galois_ntt(np.ascontiguousarray(t[d]), elt) for d in range(t.shape[0])])
+        cx = o.key_switch_inner_prod(size_ql, np.ascontiguousarray(tp), key)
+        cx[0] = addmod(cx[0], lift(src[0], elt))
+        return cx
+
+    def moddown2(x):
+        return np.stack([o.moddown_from_ntt(size_ql, np.ascontiguousarray(x[i]).copy()) for i in range(2)])
+
+    rots = [rotate_qp(ct, e, k) for e, k in zip(baby_elts, baby_keys)]
+    total = None
+    for g, (ge, gk) in enumerate(zip(giant_elts, giant_keys)):
+        acc = None
+        for b, pt in enumerate(plains[g]):
+            if pt is None:
+                continue
+            term = np.zeros((2, qlp, n), dtype=np.uint64)
+            for i in range(2):
+                for j in range(qlp):
+                    term[i, j] = _mulmod_vec(pt[j], rots[b][i, j], mods[j])
+            acc = term if acc is None else addmod(acc, term)
+        if acc is None:
+            continue
+        add = acc if ge == 1 else rotate_qp(moddown2(acc), ge, gk)
+        total = add if total is None else addmod(total, add)
+    return moddown2(total)

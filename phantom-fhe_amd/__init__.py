@@ -93,6 +93,9 @@ SIGNATURES = {
     "pha_ckks_encode": (_int, [_vp, _vp, _sz, _sz, _sz, ctypes.c_double, _vp, _vp]),
     "pha_ckks_decode": (_int, [_vp, _vp, _sz, ctypes.c_double, _sz, _vp, _vp]),
     "pha_rotate_hoisted": (_int, [_vp, _sz, _vp, _sz, _u32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
+    "pha_ckks_encode_qp": (_int, [_vp, _vp, _sz, _sz, _sz, ctypes.c_double, _vp, _vp]),
+    "pha_linear_transform_double_hoisted": (_int, [_vp, _sz, _vp, _sz, _u32p, ctypes.POINTER(_vp), _sz, _u32p, ctypes.POINTER(_vp),
+                                                   ctypes.POINTER(_vp), _vp, _vp]),
     "pha_mod_raise": (_int, [_vp, _vp, _vp, _vp]),
     "pha_gen_secretkey_sparse": (_int, [_vp, _u64, _sz, _vp, _vp]),
     "pha_lp_modup_begin": (_int, [_vp, _sz, _vp, _vp, _sz, _sz, _vp]),
@@ -383,6 +386,14 @@ class PhantomContext:
                                      _stream()))
         return plain
 
+    def encode_qp(self, values, scale, chain_index=1, sparse_slots=0):
+        """plaintext over Q_l u P, [l + size_P][N]: the operand format of linear_transform_double_hoisted"""
+        v = np.ascontiguousarray(values, dtype=np.complex128)
+        plain = self._empty(self.level_limbs(chain_index) + self.size_P)
+        _check(lib().pha_ckks_encode_qp(self._h, v.ctypes.data, v.size, sparse_slots, chain_index, float(scale), _ptr(plain),
+                                        _stream()))
+        return plain
+
     def decode(self, plain, scale, sparse_slots, chain_index=1):
         out = np.zeros(sparse_slots, dtype=np.complex128)
         _check(lib().pha_ckks_decode(self._h, _ptr(plain), chain_index, float(scale), sparse_slots, out.ctypes.data,
@@ -472,6 +483,20 @@ class PhantomContext:
         out_ptrs = (_vp * len(outs))(*[o.data_ptr() for o in outs])
         _check(lib().pha_rotate_hoisted(self._h, chain_index, _ptr(ct), len(outs), elts, keys, out_ptrs, _stream()))
         return outs
+
+    def linear_transform_double_hoisted(self, chain_index, ct, baby_elts, baby_keys, giant_elts, giant_keys, plains):
+        """sum_g rot_G( sum_b plains[g][b] * rot_B(ct) ) with one modup for the babies and one moddown per giant step
+        (include/phantom_amd.h).  Galois element 1 = no rotation (key None); plains[g][b] = encode_qp plaintext or None."""
+        out = self._empty(2, ct.shape[1])
+        nb, ng = len(baby_elts), len(giant_elts)
+        be, ge = (_u32 * nb)(*baby_elts), (_u32 * ng)(*giant_elts)
+        bk = (_vp * nb)(*[k.ptr if k is not None else None for k in baby_keys])
+        gk = (_vp * ng)(*[k.ptr if k is not None else None for k in giant_keys])
+        flat = [plains[g][b] for g in range(ng) for b in range(nb)]
+        pp = (_vp * (nb * ng))(*[p.data_ptr() if p is not None else None for p in flat])
+        _check(lib().pha_linear_transform_double_hoisted(self._h, chain_index, _ptr(ct), nb, be, bk, ng, ge, gk, pp, _ptr(out),
+                                                         _stream()))
+        return out
 
     # limb-parallel steps (include/phantom_amd.h "limb-parallel key switch"); w = (q_begin, q_count,
     # p_begin, p_count), orchestrated by limb_parallel.LimbParallelEvaluator ------------------

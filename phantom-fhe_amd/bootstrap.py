@@ -44,35 +44,21 @@ class LinearTransform:
         self.n1 = 1 << math.ceil(math.log2(s) / 2)
         self.n2 = s // self.n1
         j = np.arange(s)
-        self.diags = {}
+        self.plains = [[None] * self.n1 for _ in range(self.n2)]       # [giant][baby]
         for g in range(self.n2):
             for b in range(self.n1):
                 d = g * self.n1 + b
                 diag = matrix[j, (j + d) % s]
                 if np.abs(diag).max() < 1e-300:
                     continue
-                self.diags[(g, b)] = ev.encode(np.roll(diag, g * self.n1), diag_scale, level, s)
+                self.plains[g][b] = ev.encode_lt(np.roll(diag, g * self.n1), diag_scale, level, s)
 
     def steps(self):
         return [b for b in range(1, self.n1)] + [g * self.n1 for g in range(1, self.n2)]
 
     def apply(self, ct):
         ev = self.ev
-        ct = ev.drop(ct, self.level)
-        babies = ev.rotate_many(ct, list(range(self.n1)))          # one hoisted modup for all baby steps
-        total = None
-        for g in range(self.n2):
-            inner = None
-            for b in range(self.n1):
-                pt = self.diags.get((g, b))
-                if pt is None:
-                    continue
-                inner = ev.mul_plain_add(inner, babies[b], pt)
-            if inner is None:
-                continue
-            if g:
-                inner = ev.rotate(inner, g * self.n1)
-            total = inner if total is None else ev.add(total, inner)
+        total = ev.bsgs(ev.drop(ct, self.level), list(range(self.n1)), [g * self.n1 for g in range(self.n2)], self.plains)
         for _ in range(self.rescales):      # 2: diagonals encoded over two primes (double precision)
             total = ev.rescale(total)
         return total
@@ -143,8 +129,9 @@ def dense_to_diagonals(matrix):
 
 class DiagonalTransform:
     """x -> sum_d v_d * rot(x, d) on S slots with baby-step/giant-step rotations over the offsets that
-    occur (offsets are multiples of a stride: d = stride * (g * n1 + b)); the baby rotations of the input
-    share one modup.  `rescales` levels are consumed (2: diagonals encoded over two primes)."""
+    occur (offsets are multiples of a stride: d = stride * (g * n1 + b)); the evaluator's `bsgs` does the
+    sum_g rot_G(sum_b pt[g][b] * rot_B(x)) — double-hoisted on the GPU (one modup for the babies, one moddown per
+    giant step).  `rescales` levels are consumed (2: diagonals encoded over two primes)."""
 
     def __init__(self, ev, diagonals, S, level, diag_scale, rescales=1):
         self.ev, self.S, self.level, self.rescales = ev, S, level, rescales
@@ -158,29 +145,21 @@ class DiagonalTransform:
         self.stride = stride
         self.n1 = max(1, 1 << math.ceil(math.log2(max(2, len(ks))) / 2))
         self.n1 = min(self.n1, m)
-        self.terms = {}       # g -> list of (b, plaintext)
-        for d, k in zip(offs, ks):
-            g, b = divmod(k, self.n1)
+        split = {d: divmod(k, self.n1) for d, k in zip(offs, ks)}
+        self.babies = sorted({b for _, b in split.values()})
+        self.giants = sorted({g for g, _ in split.values()})
+        self.plains = [[None] * len(self.babies) for _ in self.giants]     # [giant][baby] -> plaintext
+        for d, (g, b) in split.items():
             shift = g * self.n1 * stride
-            pt = ev.encode(np.roll(diagonals[d], shift), diag_scale, level, S)
-            self.terms.setdefault(g, []).append((b, pt))
-        self.babies = sorted({b for t in self.terms.values() for b, _ in t})
+            self.plains[self.giants.index(g)][self.babies.index(b)] = ev.encode_lt(np.roll(diagonals[d], shift), diag_scale, level, S)
 
     def steps(self):
-        return [b * self.stride for b in self.babies if b] + [g * self.n1 * self.stride for g in self.terms if g]
+        return [b * self.stride for b in self.babies if b] + [g * self.n1 * self.stride for g in self.giants if g]
 
     def apply(self, ct):
         ev = self.ev
-        ct = ev.drop(ct, self.level)
-        rot = dict(zip(self.babies, ev.rotate_many(ct, [b * self.stride for b in self.babies])))
-        total = None
-        for g, terms in self.terms.items():
-            inner = None
-            for b, pt in terms:
-                inner = ev.mul_plain_add(inner, rot[b], pt)
-            if g:
-                inner = ev.rotate(inner, g * self.n1 * self.stride)
-            total = inner if total is None else ev.add(total, inner)
+        total = ev.bsgs(ev.drop(ct, self.level), [b * self.stride for b in self.babies],
+                        [g * self.n1 * self.stride for g in self.giants], self.plains)
         for _ in range(self.rescales):
             total = ev.rescale(total)
         return total

@@ -83,6 +83,28 @@ class EvaluatorBase:
     def rotate(self, a, step):
         return self.rotate_many(a, [step])[0]
 
+    # ---- baby-step / giant-step sums (the linear transforms of bootstrap.py) ----------------------------
+    def encode_lt(self, values, scale, level, sparse_slots):
+        """a diagonal of a linear transform, in the form `bsgs` consumes"""
+        return self.encode(values, scale, level, sparse_slots)
+
+    def bsgs(self, a, baby_steps, giant_steps, plains):
+        """sum_g rot_G( sum_b plains[g][b] * rot_B(a) ); plains[g][b] may be None.  Step by step here: the baby
+        rotations share one modup (rotate_many), every rotation ends in its own moddown."""
+        rot = self.rotate_many(a, baby_steps)
+        total = None
+        for g, row in zip(giant_steps, plains):
+            inner = None
+            for r, pt in zip(rot, row):
+                if pt is not None:
+                    inner = self.mul_plain_add(inner, r, pt)
+            if inner is None:
+                continue
+            if g % (self.n // 2):
+                inner = self.rotate(inner, g)
+            total = inner if total is None else self.add(total, inner)
+        return total
+
     def square_double_minus_one(self, a):
         """2a^2 - 1 (a Chebyshev doubling / a cosine double angle), one level"""
         t = self.rescale(self.double(self.mul(a, a)))
@@ -96,9 +118,10 @@ class GpuEvaluator(EvaluatorBase):
     """Every primitive is a C-ABI call on `ctx` (phantom_fhe_amd.PhantomContext).  Keys are generated
     on the GPU from `sk` for the rotations announced with `add_rotation_keys`."""
 
-    def __init__(self, pha, ctx, sk, sparse_slots, seed=1000):
+    def __init__(self, pha, ctx, sk, sparse_slots, seed=1000, double_hoisting=True):
         super().__init__(ctx.log_n, ctx.moduli[:ctx.size_Q], sparse_slots)
         self.pha, self.ctx, self.sk = pha, ctx, sk
+        self.double_hoisting = double_hoisting
         self._seed = seed
         self.rlk = ctx.gen_relinkey(sk, self._next_seed())
         self.galois = {}
@@ -123,6 +146,24 @@ class GpuEvaluator(EvaluatorBase):
     def encode(self, values, scale, level, sparse_slots=None):
         s = self.s if sparse_slots is None else sparse_slots
         return Pt(self.ctx.encode(values, scale, level, s), level, scale)
+
+    def encode_lt(self, values, scale, level, sparse_slots):
+        if not self.double_hoisting:
+            return self.encode(values, scale, level, sparse_slots)
+        return Pt(self.ctx.encode_qp(values, scale, level, sparse_slots), level, scale)       # over Q_l u P
+
+    def bsgs(self, a, baby_steps, giant_steps, plains):
+        """one C-ABI call: pha_linear_transform_double_hoisted (one modup for the babies, one moddown per giant step)"""
+        if not self.double_hoisting:
+            return super().bsgs(a, baby_steps, giant_steps, plains)
+        half = self.n // 2
+        scale = next(p.scale for row in plains for p in row if p is not None)
+        b_elts = [self.elt(s) if s % half else 1 for s in baby_steps]
+        g_elts = [self.elt(s) if s % half else 1 for s in giant_steps]
+        out = self.ctx.linear_transform_double_hoisted(
+            a.level, a.data, b_elts, [self.galois[e] if e != 1 else None for e in b_elts], g_elts,
+            [self.galois[e] if e != 1 else None for e in g_elts], [[None if p is None else p.data for p in row] for row in plains])
+        return Ct(out, a.level, a.scale * scale)
 
     def encrypt(self, pt):
         return Ct(self.ctx.encrypt_symmetric(self.sk, pt.data, pt.level, self._next_seed(), self._next_seed()), pt.level, pt.scale)

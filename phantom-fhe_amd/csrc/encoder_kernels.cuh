@@ -82,12 +82,16 @@ __device__ __forceinline__ uint64_t double_residue(double v, const DModulus &m) 
 
 // src/rns_base.cu decompose_array: coefficient t*gap of every limb <- rint of component t of u
 // (t < s: real parts, t >= s: imaginary parts); the other coefficients were zeroed
+// limbs >= size_Ql are the special primes (table index size_Q + l - size_Ql): plaintexts over Q_l u P
 __global__ __launch_bounds__(256) void ckks_decompose_kernel(uint64_t *plain, const double2 *u, const DModulus *mod,
-                                                             uint32_t limbs, uint32_t n, uint32_t s, uint32_t gap) {
+                                                             uint32_t limbs, uint32_t n, uint32_t s, uint32_t gap,
+                                                             uint32_t size_Ql, uint32_t size_Q) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= 2 * s) return;
     const double v = rint(t < s ? u[t].x : u[t - s].y);
-    for (uint32_t l = 0; l < limbs; l++) plain[static_cast<size_t>(l) * n + static_cast<size_t>(t) * gap] = double_residue(v, mod[l]);
+    for (uint32_t l = 0; l < limbs; l++)
+        plain[static_cast<size_t>(l) * n + static_cast<size_t>(t) * gap] =
+            double_residue(v, mod[l >= size_Ql ? size_Q + (l - size_Ql) : l]);
 }
 
 constexpr int kMaxCrtWords = 64;

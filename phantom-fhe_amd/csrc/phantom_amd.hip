@@ -1515,11 +1515,15 @@ int pha_mod_switch_drop_to_next(pha_context *ctx, size_t chain_index, const uint
 }
 
 // ---- CKKS encoder / decoder (src/ckks.cu:130-283) ----------------------------------------------
-int pha_ckks_encode(pha_context *ctx, const double *values_host, size_t values_size, size_t sparse_slots, size_t chain_index,
-                    double scale, uint64_t *plain, pha_stream_t stream) {
+namespace {
+// with_special: the plaintext is written over Q_l u P ([size_Ql + size_P][N]) instead of Q_l
+int do_ckks_encode(pha_context *ctx, const double *values_host, size_t values_size, size_t sparse_slots, size_t chain_index,
+                   double scale, uint64_t *plain, bool with_special, pha_stream_t stream) {
     REQUIRE_CTX(plain && (values_host || values_size == 0));
     size_t limbs;
     PHA_TRY(level_limbs(ctx, chain_index, &limbs));
+    if (with_special && (chain_index == 0 || ctx->size_P == 0))
+        return fail(PHA_ERR_INVALID_ARGUMENT, "a plaintext over Q_l u P needs a data level and a special modulus");
     if (values_size > ctx->n / 2) return fail(PHA_ERR_INVALID_ARGUMENT, "values_size is too large");
     pha_context::EncoderLevel *lv;
     PHA_TRY(get_encoder_level(ctx, limbs, &lv));
@@ -1557,14 +1561,31 @@ int pha_ckks_encode(pha_context *ctx, const double *values_host, size_t values_s
     const int max_coeff_bit_count = static_cast<int>(std::ceil(std::log2(std::max(max_coeff, 1.0)))) + 1;
     if (!(max_coeff == max_coeff) || max_coeff_bit_count >= lv->total_bits)
         return fail(PHA_ERR_INVALID_ARGUMENT, "encoded values are too large");
-    HIP_TRY(hipMemsetAsync(plain, 0, limbs * n * sizeof(uint64_t), st));
+    const size_t out_limbs = limbs + (with_special ? ctx->size_P : 0);
+    HIP_TRY(hipMemsetAsync(plain, 0, out_limbs * n * sizeof(uint64_t), st));
     hipLaunchKernelGGL(ckks_decompose_kernel, dim3((2 * S + 255) / 256), dim3(256), 0, st, plain, tmp, ctx->d_mod.p,
-                       static_cast<uint32_t>(limbs), n, S, n / (2 * S));
+                       static_cast<uint32_t>(out_limbs), n, S, n / (2 * S),
+                       static_cast<uint32_t>(chain_index == 0 ? out_limbs : limbs), static_cast<uint32_t>(ctx->size_Q));
     PHA_TRY(check_launch("ckks_decompose"));
     NttRange r;
-    PHA_TRY(make_range(ctx, limbs, 0, 0, 0, 0, 0, r));
+    if (with_special)
+        PHA_TRY(make_range(ctx, out_limbs, 0, ctx->size_QP, ctx->size_P, 0, 0, r));
+    else
+        PHA_TRY(make_range(ctx, limbs, 0, 0, 0, 0, 0, r));
     return ntt_forward(ctx, plain, 1, 0, r, EPI_NONE, Epilogue{}, st);
 }
+}  // namespace
+
+int pha_ckks_encode(pha_context *ctx, const double *values_host, size_t values_size, size_t sparse_slots, size_t chain_index,
+                    double scale, uint64_t *plain, pha_stream_t stream) {
+    return do_ckks_encode(ctx, values_host, values_size, sparse_slots, chain_index, scale, plain, false, stream);
+}
+
+int pha_ckks_encode_qp(pha_context *ctx, const double *values_host, size_t values_size, size_t sparse_slots, size_t chain_index,
+                       double scale, uint64_t *plain, pha_stream_t stream) {
+    return do_ckks_encode(ctx, values_host, values_size, sparse_slots, chain_index, scale, plain, true, stream);
+}
+
 
 int pha_ckks_decode(pha_context *ctx, const uint64_t *plain, size_t chain_index, double scale, size_t sparse_slots,
                     double *values_host, pha_stream_t stream) {
@@ -1623,6 +1644,94 @@ int pha_rotate_hoisted(pha_context *ctx, size_t chain_index, const uint64_t *ct,
         PHA_TRY(do_moddown(ctx, lt, out_host[r], cx, scratch, out_host[r], 2, st));
     }
     return PHA_OK;
+}
+
+// Double-hoisted baby-step / giant-step linear transform (Bossuat et al., "Efficient bootstrapping for approximate
+// homomorphic encryption with non-sparse keys", algorithm 6; the reference's *_hoisting drivers stop at sharing the
+// modup): out = sum_g rot_{G_g}( sum_b pt[g][b] * rot_{B_b}(ct) ).
+//   babies:  ONE modup of c1; per baby an inner product with the automorphism applied on the fly, result kept
+//            over Q_l u P with P * pi(c0) added on the Q_l limbs — no moddown;
+//   giants:  the inner sum is one multi-term multiply-accumulate over Q_l u P (plaintexts encoded over Q_l u P by
+//            pha_ckks_encode_qp), ONE moddown (both polys), then for G != identity modup + inner product, the
+//            results accumulated over Q_l u P;
+//   end:     ONE moddown of the total.
+// Moddowns: n_giant + 1 instead of n_baby + n_giant.  Galois element 1 = no rotation (its key may be null).
+int pha_linear_transform_double_hoisted(pha_context *ctx, size_t chain_index, const uint64_t *ct, size_t n_baby,
+                                        const uint32_t *baby_elts_host, const uint64_t *const *const *baby_evks_host,
+                                        size_t n_giant, const uint32_t *giant_elts_host,
+                                        const uint64_t *const *const *giant_evks_host, const uint64_t *const *plains_host,
+                                        uint64_t *out, pha_stream_t stream) {
+    REQUIRE_CTX(ct && baby_elts_host && baby_evks_host && giant_elts_host && giant_evks_host && plains_host && out);
+    if (n_baby == 0 || n_baby > kMaxMacTerms || n_giant == 0)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "baby steps must number 1..%d, giant steps at least 1", kMaxMacTerms);
+    if (ctx->size_P == 0) return fail(PHA_ERR_LOGIC, "key switching needs a special modulus");
+    LevelTool *lt;
+    PHA_TRY(get_level(ctx, chain_index, &lt));
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, size_QlP = size_Ql + ctx->size_P;
+    hipStream_t st = as_stream(stream);
+    if (!ctx->d_bigP_mod_q.p) {
+        LevelConstants lc;
+        build_level_constants(ctx->moduli, ctx->size_P, ctx->size_Q, lc);
+        HIP_TRY(ctx->d_bigP_mod_q.upload(lc.bigP_mod_q));
+    }
+    uint64_t *ws;
+    PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + (2 * n_baby + 6) * size_QlP + 4 * size_Ql) * n, &ws));
+    uint64_t *t_mod_up = ws, *cx = t_mod_up + lt->beta * size_QlP * n, *acc = cx + 2 * size_QlP * n,
+             *total = acc + 2 * size_QlP * n, *rot = total + 2 * size_QlP * n, *scratch = rot + 2 * n_baby * size_QlP * n,
+             *u = scratch + 2 * size_Ql * n;
+    const uint32_t n32 = static_cast<uint32_t>(n), ql = static_cast<uint32_t>(size_Ql), qlp = static_cast<uint32_t>(size_QlP),
+                   sq = static_cast<uint32_t>(ctx->size_Q);
+    const dim3 grid_qp(qlp * (n32 / 512), 2), grid_qp1(qlp * (n32 / 512), 1);
+    const DModulus *mod = ctx->d_mod.p;
+    auto perm_of = [&](uint32_t elt, const uint32_t **perm) -> int {
+        *perm = nullptr;
+        return elt == 1 ? PHA_OK : get_galois_table(ctx, elt, perm);
+    };
+    // dst_qp = key switch of src's c1 under elt (t_mod_up must hold modup(src c1)) + lifted pi(c0)
+    auto rotate_qp = [&](uint64_t *dst_qp, const uint64_t *src, uint32_t elt, const uint64_t *const *evks) -> int {
+        const uint32_t *perm;
+        PHA_TRY(perm_of(elt, &perm));
+        if (elt == 1) {
+            hipLaunchKernelGGL((lift_qp_kernel<true>), grid_qp, dim3(256), 0, st, dst_qp, src, perm, ctx->d_bigP_mod_q.p, mod, n32, ql, qlp);
+            return check_launch("lift_qp");
+        }
+        if (!evks) return fail(PHA_ERR_INVALID_ARGUMENT, "null Galois key");
+        PHA_TRY(do_inner_prod(ctx, lt, dst_qp, t_mod_up, evks, st, perm));
+        hipLaunchKernelGGL((lift_qp_kernel<false>), grid_qp1, dim3(256), 0, st, dst_qp, src, perm, ctx->d_bigP_mod_q.p, mod, n32, ql, qlp);
+        return check_launch("lift_qp");
+    };
+    bool any_rot = false;
+    for (size_t b = 0; b < n_baby; b++) any_rot = any_rot || baby_elts_host[b] != 1;
+    if (any_rot) PHA_TRY(do_modup(ctx, lt, t_mod_up, ct + size_Ql * n, scratch, st));
+    for (size_t b = 0; b < n_baby; b++) PHA_TRY(rotate_qp(rot + 2 * b * size_QlP * n, ct, baby_elts_host[b], baby_evks_host[b]));
+    bool first = true;
+    for (size_t g = 0; g < n_giant; g++) {
+        MacTerms terms{};
+        for (size_t b = 0; b < n_baby; b++) {
+            const uint64_t *pt = plains_host[g * n_baby + b];
+            if (!pt) continue;
+            terms.rot[terms.count] = rot + 2 * b * size_QlP * n;
+            terms.pt[terms.count++] = pt;
+        }
+        if (!terms.count) continue;
+        hipLaunchKernelGGL(multi_mac_qp_kernel, dim3(qlp * (n32 / 512)), dim3(256), 0, st, acc, terms, mod, n32, ql, qlp, sq);
+        PHA_TRY(check_launch("multi_mac_qp"));
+        const uint64_t *add = acc;
+        if (giant_elts_host[g] != 1) {
+            PHA_TRY(do_moddown(ctx, lt, u, acc, scratch, nullptr, 2, st));
+            PHA_TRY(do_modup(ctx, lt, t_mod_up, u + size_Ql * n, scratch, st));
+            PHA_TRY(rotate_qp(cx, u, giant_elts_host[g], giant_evks_host[g]));
+            add = cx;
+        }
+        if (first)
+            hipLaunchKernelGGL((add_qp_kernel<true>), grid_qp, dim3(256), 0, st, total, add, mod, n32, ql, qlp, sq);
+        else
+            hipLaunchKernelGGL((add_qp_kernel<false>), grid_qp, dim3(256), 0, st, total, add, mod, n32, ql, qlp, sq);
+        PHA_TRY(check_launch("add_qp"));
+        first = false;
+    }
+    if (first) return fail(PHA_ERR_INVALID_ARGUMENT, "the transform has no plaintext");
+    return do_moddown(ctx, lt, out, total, scratch, nullptr, 2, st);
 }
 
 // ---- bootstrapping primitives (src/boot/Bootstrapper.cu) ------------------------------------------

@@ -198,6 +198,90 @@ __global__ __launch_bounds__(256) void key_switch_inner_prod_kernel(uint64_t *ds
     *reinterpret_cast<ulonglong2 *>(dst + size_QlP_n + c2_id) = r1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Double-hoisted linear transforms (pha_linear_transform_double_hoisted): rotated ciphertexts stay in the
+// extended basis Q_l u P between the key-switch inner product and ONE moddown per giant step.
+// Buffers over Q_l u P are [polys][size_QlP][n]; buffer limb j uses modulus j (j < size_Ql) or
+// size_Q + (j - size_Ql).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t qp_table_index(uint32_t limb, uint32_t size_Ql, uint32_t size_Q) {
+    return limb >= size_Ql ? size_Q + (limb - size_Ql) : limb;
+}
+
+// dst[p][j][i] (+)= (P mod q_j) * src[p][j][perm ? perm[i] : i] on the Q_l limbs: the ciphertext part that a key
+// switch leaves untouched, lifted to Q_l u P (its P limbs are zero).  SET also zeroes the P limbs.
+template <bool SET>
+__global__ __launch_bounds__(256) void lift_qp_kernel(uint64_t *dst, const uint64_t *src, const uint32_t *perm,
+                                                      const uint64_t *bigP_mod_q, const DModulus *mod, uint32_t n,
+                                                      uint32_t size_Ql, uint32_t size_QlP) {
+    const uint32_t per_limb = n / 512;
+    const uint32_t poly = blockIdx.y, limb = blockIdx.x / per_limb;
+    const uint32_t k = ((blockIdx.x % per_limb) * 256 + threadIdx.x) * 2;
+    uint64_t *d = dst + (static_cast<size_t>(poly) * size_QlP + limb) * n + k;
+    if (limb >= size_Ql) {
+        if (SET) *reinterpret_cast<ulonglong2 *>(d) = ulonglong2{0, 0};
+        return;
+    }
+    const uint64_t *row = src + (static_cast<size_t>(poly) * size_Ql + limb) * n;
+    const DModulus m = mod[limb];
+    const uint64_t pj = bigP_mod_q[limb];
+    ulonglong2 v;
+    v.x = mul_barrett(perm ? row[perm[k]] : row[k], pj, m);
+    v.y = mul_barrett(perm ? row[perm[k + 1]] : row[k + 1], pj, m);
+    if (!SET) {
+        const ulonglong2 o = *reinterpret_cast<const ulonglong2 *>(d);
+        v.x = csub(v.x + o.x, m.value);
+        v.y = csub(v.y + o.y, m.value);
+    }
+    *reinterpret_cast<ulonglong2 *>(d) = v;
+}
+
+constexpr int kMaxMacTerms = 32;
+struct MacTerms {
+    const uint64_t *rot[kMaxMacTerms];  // [2][size_QlP][n] each
+    const uint64_t *pt[kMaxMacTerms];   // [size_QlP][n] each
+    uint32_t count;
+};
+
+// dst[p][j][i] = sum_b pt_b[j][i] * rot_b[p][j][i] mod q_j, both polys: the inner sum of a giant step, one pass
+__global__ __launch_bounds__(256) void multi_mac_qp_kernel(uint64_t *dst, MacTerms terms, const DModulus *mod, uint32_t n,
+                                                           uint32_t size_Ql, uint32_t size_QlP, uint32_t size_Q) {
+    const uint32_t per_limb = n / 512;
+    const uint32_t limb = blockIdx.x / per_limb;
+    const uint32_t k = ((blockIdx.x % per_limb) * 256 + threadIdx.x) * 2;
+    const DModulus m = mod[qp_table_index(limb, size_Ql, size_Q)];
+    const size_t id = static_cast<size_t>(limb) * n + k, poly1 = static_cast<size_t>(size_QlP) * n;
+    u128_t a0x = {0, 0}, a0y = {0, 0}, a1x = {0, 0}, a1y = {0, 0};
+    for (uint32_t b = 0; b < terms.count; b++) {
+        const ulonglong2 pt = *reinterpret_cast<const ulonglong2 *>(terms.pt[b] + id);
+        const ulonglong2 r0 = *reinterpret_cast<const ulonglong2 *>(terms.rot[b] + id);
+        const ulonglong2 r1 = *reinterpret_cast<const ulonglong2 *>(terms.rot[b] + poly1 + id);
+        add128(a0x, mul64x64(pt.x, r0.x));
+        add128(a0y, mul64x64(pt.y, r0.y));
+        add128(a1x, mul64x64(pt.x, r1.x));
+        add128(a1y, mul64x64(pt.y, r1.y));
+    }
+    *reinterpret_cast<ulonglong2 *>(dst + id) = ulonglong2{barrett128(a0x, m), barrett128(a0y, m)};
+    *reinterpret_cast<ulonglong2 *>(dst + poly1 + id) = ulonglong2{barrett128(a1x, m), barrett128(a1y, m)};
+}
+
+// dst += src over [2][size_QlP][n] (SET: dst = src)
+template <bool SET>
+__global__ __launch_bounds__(256) void add_qp_kernel(uint64_t *dst, const uint64_t *src, const DModulus *mod, uint32_t n,
+                                                     uint32_t size_Ql, uint32_t size_QlP, uint32_t size_Q) {
+    const uint32_t per_limb = n / 512;
+    const uint32_t poly = blockIdx.y, limb = blockIdx.x / per_limb;
+    const size_t id = (static_cast<size_t>(poly) * size_QlP + limb) * n + ((blockIdx.x % per_limb) * 256 + threadIdx.x) * 2;
+    ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + id);
+    if (!SET) {
+        const uint64_t q = mod[qp_table_index(limb, size_Ql, size_Q)].value;
+        const ulonglong2 o = *reinterpret_cast<const ulonglong2 *>(dst + id);
+        v.x = csub(v.x + o.x, q);
+        v.y = csub(v.y + o.y, q);
+    }
+    *reinterpret_cast<ulonglong2 *>(dst + id) = v;
+}
+
 // ct[l][k] = ct[l][k] + cx[l][k] mod q_l (src/rns_bconv.cu:763-769)
 __global__ __launch_bounds__(256) void add_to_ct_kernel(uint64_t *ct, const uint64_t *cx, const DModulus *mod,
                                                         uint32_t n) {

@@ -98,6 +98,42 @@ public:
         encoder->encode_slots(*context, values, slots, sc, p, level, stream);
         return p;
     }
+    // plaintext over Q_l u P: the operand format of the double-hoisted linear transforms
+    PhantomPlaintext encode_qp(const cvec &values, double sc, size_t level, size_t slots) {
+        PhantomPlaintext p;
+        p.resize(context->coeff_mod_size(level) + context->size_P(), n(), s());
+        check(pha_ckks_encode_qp(h(), reinterpret_cast<const double *>(values.data()), values.size(), slots, level, sc, p.data(), s()));
+        p.set_chain_index(level);
+        p.set_scale(sc);
+        return p;
+    }
+    // sum_g rot_G( sum_b plains[g * n_baby + b] * rot_B(a) ), double-hoisted: ONE C-ABI call (one modup for the
+    // babies, one moddown per giant step).  Steps that are multiples of N/2 do not rotate; plains entries may be null.
+    PhantomCiphertext bsgs(const PhantomCiphertext &a, const std::vector<int> &baby_steps, const std::vector<int> &giant_steps,
+                           const std::vector<const PhantomPlaintext *> &plains) {
+        const int half = static_cast<int>(n() >> 1);
+        std::vector<uint32_t> be, ge;
+        std::vector<const uint64_t *const *> bk, gk;
+        auto fill = [&](const std::vector<int> &steps, std::vector<uint32_t> &elts, std::vector<const uint64_t *const *> &keys) {
+            for (int st : steps) {
+                const uint32_t e = st % half ? elt(st) : 1u;
+                elts.push_back(e);
+                keys.push_back(e == 1 ? nullptr : galois_keys->get_relin_keys(e).public_keys_ptr());
+            }
+        };
+        fill(baby_steps, be, bk);
+        fill(giant_steps, ge, gk);
+        std::vector<const uint64_t *> pp;
+        double pscale = 0;
+        for (const PhantomPlaintext *p : plains) {
+            pp.push_back(p ? p->data() : nullptr);
+            if (p) pscale = p->scale();
+        }
+        PhantomCiphertext d = make(a.chain_index(), a.scale() * pscale);
+        check(pha_linear_transform_double_hoisted(h(), a.chain_index(), a.data(), be.size(), be.data(), bk.data(), ge.size(), ge.data(),
+                                                  gk.data(), pp.data(), d.data(), s()));
+        return d;
+    }
     PhantomCiphertext encrypt(const PhantomPlaintext &p) {
         PhantomCiphertext c;
         secret_key->encrypt_symmetric(*context, p, c, stream);
@@ -360,14 +396,15 @@ inline std::vector<DiagMap> special_fft_groups(int S, int n_groups, bool inverse
 }
 
 // x -> sum_d v_d * rot(x, d) on S slots: baby-step / giant-step over the offsets that occur (multiples of one
-// stride), hoisted baby rotations, fused multiply-accumulate; one level
+// stride), evaluated double-hoisted by one library call; one level
 class DiagonalTransform {
     CKKSEvaluator *ev_;
     int S_, stride_ = 1, n1_ = 1;
     size_t level_;
     DiagMap diagonals_;
-    std::map<int, std::vector<std::pair<int, PhantomPlaintext>>> terms_;  // giant g -> (baby b, plaintext)
-    std::vector<int> babies_;
+    std::vector<int> babies_, giants_;          // baby / giant indices that occur (units of stride, of n1 * stride)
+    std::vector<PhantomPlaintext> plains_;      // encoded diagonals over Q_l u P
+    std::vector<const PhantomPlaintext *> table_;  // [giant][baby] -> plaintext or null
 
 public:
     DiagonalTransform(CKKSEvaluator *ev, DiagMap diagonals, int S, size_t level) : ev_(ev), S_(S), level_(level), diagonals_(std::move(diagonals)) {
@@ -379,50 +416,45 @@ public:
         const double cnt = std::max<double>(2.0, static_cast<double>(diagonals_.size()));
         n1_ = std::max(1, 1 << static_cast<int>(std::ceil(std::log2(cnt) / 2.0)));
         n1_ = std::min(n1_, m);
-        std::set<int> babies;
-        for (const auto &d : diagonals_) babies.insert((d.first / stride_) % n1_);
+        std::set<int> babies, giants;
+        for (const auto &d : diagonals_) {
+            babies.insert((d.first / stride_) % n1_);
+            giants.insert((d.first / stride_) / n1_);
+        }
         babies_.assign(babies.begin(), babies.end());
+        giants_.assign(giants.begin(), giants.end());
     }
     size_t level() const { return level_; }
     std::vector<int> steps() const {
         std::vector<int> out;
         for (int b : babies_)
             if (b) out.push_back(b * stride_);
-        std::set<int> giants;
-        for (const auto &d : diagonals_) giants.insert((d.first / stride_) / n1_);
-        for (int g : giants)
+        for (int g : giants_)
             if (g) out.push_back(g * n1_ * stride_);
         return out;
     }
-    // encode the diagonals (rotated back by their giant step) at diag_scale
+    // encode the diagonals (rotated back by their giant step) at diag_scale, over Q_l u P
     void encode(double diag_scale) {
-        terms_.clear();
+        plains_.clear();
+        plains_.reserve(diagonals_.size());
+        table_.assign(giants_.size() * babies_.size(), nullptr);
         for (const auto &d : diagonals_) {
             const int k = d.first / stride_, g = k / n1_, b = k % n1_, shift = g * n1_ * stride_;
             cvec rolled(S_);
             for (int j = 0; j < S_; j++) rolled[j] = d.second[((j - shift) % S_ + S_) % S_];
-            terms_[g].emplace_back(b, ev_->encode(rolled, diag_scale, level_, static_cast<size_t>(S_)));
+            plains_.push_back(ev_->encode_qp(rolled, diag_scale, level_, static_cast<size_t>(S_)));
+            const size_t gi = std::lower_bound(giants_.begin(), giants_.end(), g) - giants_.begin();
+            const size_t bi = std::lower_bound(babies_.begin(), babies_.end(), b) - babies_.begin();
+            table_[gi * babies_.size() + bi] = &plains_.back();
         }
     }
     PhantomCiphertext apply(const PhantomCiphertext &in) {
         PhantomCiphertext tmp;
         const PhantomCiphertext &ct = ev_->at_level(in, level_, tmp);
-        std::vector<int> steps;
-        for (int b : babies_) steps.push_back(b * stride_);
-        std::vector<PhantomCiphertext> rot = ev_->rotate_many(ct, steps);
-        std::map<int, const PhantomCiphertext *> by_baby;
-        for (size_t i = 0; i < babies_.size(); i++) by_baby[babies_[i]] = &rot[i];
-        PhantomCiphertext total;
-        for (auto &gt : terms_) {
-            PhantomCiphertext inner;
-            for (auto &bp : gt.second) ev_->mul_plain_add(inner, *by_baby.at(bp.first), bp.second);
-            if (gt.first) inner = ev_->rotate(inner, gt.first * n1_ * stride_);
-            if (total.data() == nullptr)
-                total = std::move(inner);
-            else
-                ev_->add_inplace(total, inner);
-        }
-        return ev_->rescale(total);
+        std::vector<int> bs, gs;
+        for (int b : babies_) bs.push_back(b * stride_);
+        for (int g : giants_) gs.push_back(g * n1_ * stride_);
+        return ev_->rescale(ev_->bsgs(ct, bs, gs, table_));
     }
 };
 

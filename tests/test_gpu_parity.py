@@ -252,6 +252,43 @@ def test_tensor_and_multiply_relin(gpu, pha, small):
     assert (_host(pha, d_ct1)[:2] == exp).all()
 
 
+@pytest.mark.parametrize("size_p,chain_index", [(2, 1), (2, 3), (1, 2), (3, 1)])
+def test_double_hoisted_linear_transform(gpu, pha, orc, size_p, chain_index):
+    """pha_linear_transform_double_hoisted against its restatement from the oracle's primitives (bit-exact; uniform
+    stand-ins for keys and plaintexts are enough for arithmetic parity): identity and rotating babies / giants,
+    absent diagonals, alpha = 1 and alpha > 1, ragged last digit."""
+    from oracle.ckks_ref import linear_transform_double_hoisted_ref
+    mods = orc.coeff_modulus_create(4096, [45] * 6 + [55] * size_p)
+    ctx, o = pha.PhantomContext(12, mods, size_p), orc.Oracle(12, mods, size_p)
+    size_ql = ctx.size_Ql(chain_index)
+    tq = list(range(size_ql))
+    tqp = tq + [o.size_Q + i for i in range(size_p)]
+    ct = np.stack([o.uniform_poly(tq, 401), o.uniform_poly(tq, 402)])
+    baby_elts = [1] + [orc.galois_elt_from_step(12, s) for s in (1, 2)]
+    giant_elts = [1, orc.galois_elt_from_step(12, 4)]
+    keys = {e: _uniform_evk(pha, o, 500 + 7 * i) for i, e in enumerate(baby_elts[1:] + giant_elts[1:])}
+    plains = [[o.uniform_poly(tqp, 600 + 10 * g + b) if (g, b) != (1, 1) else None for b in range(3)] for g in range(2)]
+    ref = linear_transform_double_hoisted_ref(o, size_ql, ct, baby_elts, [keys[e][0] if e != 1 else None for e in baby_elts],
+                                              giant_elts, [keys[e][0] if e != 1 else None for e in giant_elts], plains)
+    d_pl = [[_dev(pha, p) if p is not None else None for p in row] for row in plains]
+    out = ctx.linear_transform_double_hoisted(chain_index, _dev(pha, ct), baby_elts,
+                                              [keys[e][1] if e != 1 else None for e in baby_elts], giant_elts,
+                                              [keys[e][1] if e != 1 else None for e in giant_elts], d_pl)
+    assert (_host(pha, out) == ref).all()
+    # a transform whose only giant step rotates, and one without any rotation
+    out = ctx.linear_transform_double_hoisted(chain_index, _dev(pha, ct), baby_elts[:2], [None, keys[baby_elts[1]][1]],
+                                              giant_elts[1:], [keys[giant_elts[1]][1]], [d_pl[1][:2]])
+    ref = linear_transform_double_hoisted_ref(o, size_ql, ct, baby_elts[:2], [None, keys[baby_elts[1]][0]], giant_elts[1:],
+                                              [keys[giant_elts[1]][0]], [plains[1][:2]])
+    assert (_host(pha, out) == ref).all()
+    out = ctx.linear_transform_double_hoisted(chain_index, _dev(pha, ct), [1], [None], [1], [None], [[d_pl[0][0]]])
+    ref = linear_transform_double_hoisted_ref(o, size_ql, ct, [1], [None], [1], [None], [[plains[0][0]]])
+    assert (_host(pha, out) == ref).all()
+    with pytest.raises(pha.PhantomError):
+        ctx.linear_transform_double_hoisted(chain_index, _dev(pha, ct), [1], [None], [1], [None], [[None]])
+    ctx.close()
+
+
 def test_bad_chain_index(gpu, pha, small):
     ctx, o = small
     import torch
