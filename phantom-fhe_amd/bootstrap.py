@@ -133,8 +133,10 @@ class DiagonalTransform:
     sum_g rot_G(sum_b pt[g][b] * rot_B(x)) — double-hoisted on the GPU (one modup for the babies, one moddown per
     giant step).  `rescales` levels are consumed (2: diagonals encoded over two primes)."""
 
-    def __init__(self, ev, diagonals, S, level, diag_scale, rescales=1):
+    def __init__(self, ev, diagonals, S, level, diag_scale, rescales=1, baby_bias=None):
         self.ev, self.S, self.level, self.rescales = ev, S, level, rescales
+        if baby_bias is None:       # log2 of (cost of a giant step / cost of a baby step)
+            baby_bias = getattr(ev, "baby_bias", 0)
         offs = sorted(diagonals)
         stride = S
         for d in offs:
@@ -143,7 +145,7 @@ class DiagonalTransform:
         m = S // stride
         ks = [d // stride for d in offs]
         self.stride = stride
-        self.n1 = max(1, 1 << math.ceil(math.log2(max(2, len(ks))) / 2))
+        self.n1 = max(1, 1 << math.ceil((math.log2(max(2, len(ks))) + baby_bias) / 2))
         self.n1 = min(self.n1, m)
         split = {d: divmod(k, self.n1) for d, k in zip(offs, ks)}
         self.babies = sorted({b for _, b in split.values()})
@@ -379,10 +381,11 @@ class Bootstrapper:
     def levels_needed(self):
         return self.out_level
 
-    def eval_mod(self, w):
+    def eval_mod(self, w, ev=None):
         """w in [-1, 1] real slots, w = (m/q0 + I)/Kb  ->  sin(2 pi (m/q0 + I)) ~ 2 pi m / q0"""
-        ev = self.ev
-        c = self.cheb(w, self.delta)
+        ev = self.ev if ev is None else ev
+        cheb = self.cheb if ev is self.ev else ChebyshevEvaluator(ev, self.cheb.c, self.cheb.l)
+        c = cheb(w, self.delta)
         for _ in range(self.r):
             c = ev.square_double_minus_one(c)
         return c
@@ -407,7 +410,9 @@ class Bootstrapper:
         else:                                                 # half: (x_k + i x_{k+s}) / (2 Kb)
             re = ev.add(half, cj)
             im = ev.neg(ev.mul_i(ev.sub(half, cj)))
-            v = ev.add(self.eval_mod(re), ev.mul_i(self.eval_mod(im)))   # 2 pi (m_k + i m_{k+s}) / q0
+            # two independent EvalMods: side by side where the evaluator can (two streams on the GPU)
+            a, b = ev.run_pair(lambda e: self.eval_mod(re, e), lambda e: self.eval_mod(im, e))
+            v = ev.add(a, ev.mul_i(b))                            # 2 pi (m_k + i m_{k+s}) / q0
         out = v
         for lt in self.s2c:
             out = lt.apply(out)                           # slots: message * in_scale / delta

@@ -414,7 +414,9 @@ public:
         stride_ = stride;
         const int m = S / stride;
         const double cnt = std::max<double>(2.0, static_cast<double>(diagonals_.size()));
-        n1_ = std::max(1, 1 << static_cast<int>(std::ceil(std::log2(cnt) / 2.0)));
+        // a baby step (one inner product) is several times cheaper than a giant step (moddown + modup + inner
+        // product): one more bit of baby steps than the square-root split (measured: 31.3 -> 30.5 ms at N = 2^16)
+        n1_ = std::max(1, 1 << static_cast<int>(std::ceil((std::log2(cnt) + 1.0) / 2.0)));
         n1_ = std::min(n1_, m);
         std::set<int> babies, giants;
         for (const auto &d : diagonals_) {
