@@ -24,7 +24,10 @@ namespace pha {
 //  * PHA_TILE_LOG=11 (128 threads, 16 KiB LDS, eight to nine workgroups per CU): row kernels unchanged (18.1 us),
 //    column kernels 23.3 us against 17.4 us — their global accesses shrink to half cache lines;
 //  * PHA_LDS_SWIZZLE=1 (unpadded 32 KiB image, 96 VGPRs) does NOT reach five workgroups per CU: a CU hands out
-//    LDS to five workgroups only up to 31 KiB each (tools/scratch/occ.hip: 31744 B -> 5 resident, 32256 B -> 4).
+//    LDS to five workgroups only up to 31 KiB each (tools/scratch/occ.hip: 31744 B -> 5 resident, 32256 B -> 4);
+//  * a timing-only build with a 30 KiB image (what keeping each lane's own element of the exchange in a register
+//    would allow) did put all 1152 workgroups on the chip at once, but the kernel span only went from 16.6 to
+//    15.2 us: every workgroup ran slower (median 9.1 against 7.7 us) — the memory system, not the tail, is the limit.
 // Both stay selectable for re-measurement; every variant passes the parity tests.
 #ifndef PHA_TILE_LOG
 #define PHA_TILE_LOG 12

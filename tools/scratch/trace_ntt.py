@@ -22,6 +22,15 @@ fwd()
 torch.cuda.synchronize()
 for _ in range(10): fwd()
 torch.cuda.synchronize()
+# timing loop (no tracing)
+import time
+for ph, name in ((0, "col"), (1, "row")):
+    for inv in (0, 1):
+        f = lambda: ctx.ntt_launch_phase(x, 2, L, L, 0, inv, ph)
+        for _ in range(20): f()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(200): f()
+        torch.cuda.synchronize(); print("phase", name, "inverse" if inv else "forward", "%.2f us" % ((time.perf_counter() - t0) / 200 * 1e6), flush=True)
 assert lib.pha_set_trace(buf.data_ptr()) == 0
 torch.cuda.synchronize()
 fwd()
