@@ -52,6 +52,9 @@ public:
 private:
     std::map<std::tuple<double, double, double, size_t>, PhantomPlaintext> consts_;
     std::map<size_t, device_words> mono_;
+    std::unique_ptr<PhantomContext> sibling_context_;
+    std::unique_ptr<CKKSEvaluator> sibling_;
+    hipEvent_t fork_ = nullptr, join_ = nullptr;
     const hipStream_t &s() const { return stream.get_stream(); }
     pha_context *h() const { return context->handle(); }
     static void same(const PhantomCiphertext &a, const PhantomCiphertext &b) {
@@ -70,6 +73,35 @@ public:
                   PhantomRelinKey *relin_keys_, PhantomGaloisKey *galois_keys_, double scale_)
         : context(context_), secret_key(secret_key_), encoder(encoder_), relin_keys(relin_keys_), galois_keys(galois_keys_),
           scale(scale_) {}
+
+    ~CKKSEvaluator() {
+        if (fork_) (void)hipEventDestroy(fork_);
+        if (join_) (void)hipEventDestroy(join_);
+    }
+    // An evaluator with the same keys on its own library context (own workspace) and HIP stream.  Two independent
+    // sub-circuits at 15-30 limbs each fill less than half of the GPU: side by side they take little more than one.
+    CKKSEvaluator &sibling() {
+        if (!sibling_) {
+            sibling_context_ = std::make_unique<PhantomContext>(context->key_parms());
+            sibling_ = std::make_unique<CKKSEvaluator>(sibling_context_.get(), secret_key, encoder, relin_keys, galois_keys, scale);
+            check_hip(hipEventCreateWithFlags(&fork_, hipEventDisableTiming), "hipEventCreate");
+            check_hip(hipEventCreateWithFlags(&join_, hipEventDisableTiming), "hipEventCreate");
+        }
+        return *sibling_;
+    }
+    // (fa(*this), fb(sibling())) concurrently; both results are usable on this evaluator's stream afterwards
+    template <class FA, class FB>
+    std::pair<PhantomCiphertext, PhantomCiphertext> run_pair(FA &&fa, FB &&fb) {
+        CKKSEvaluator &sib = sibling();
+        check_hip(hipEventRecord(fork_, s()), "hipEventRecord");
+        check_hip(hipStreamWaitEvent(sib.s(), fork_, 0), "hipStreamWaitEvent");
+        PhantomCiphertext b = fb(sib);
+        check_hip(hipEventRecord(join_, sib.s()), "hipEventRecord");
+        PhantomCiphertext a = fa(*this);
+        check_hip(hipStreamWaitEvent(s(), join_, 0), "hipStreamWaitEvent");
+        b.touch(s());  // allocated on the sibling's stream, consumed (and released) on this one
+        return {std::move(a), std::move(b)};
+    }
 
     size_t n() const { return context->poly_degree(); }
     size_t limbs(size_t level) const { return context->coeff_mod_size(level); }
@@ -603,10 +635,12 @@ public:
     CKKSEvaluator *ckks = nullptr;
     std::vector<long> slot_vec;
     int lt_levels = 3;        // groups per linear transform (the "_3" of the reference's API)
+    bool concurrent_evalmod = true;  // real and imaginary EvalMod on two (context, stream) pairs
     double evalmod_scale = 0;  // 0: the power of two nearest to the first EvalMod prime
 
 private:
-    ChebyshevEvaluator cheb_;
+    ChebyshevEvaluator cheb_, cheb_sibling_;
+    std::vector<double> cheb_coeffs_;
     std::vector<DiagonalTransform> c2s_, s2c_;
     size_t evalmod_level_ = 0, s2c_level_ = 0, out_level_ = 0;
     double delta_ = 0, Kb_ = 0;
@@ -629,9 +663,9 @@ private:
         lvl = s2c_level_;
         for (auto &g : special_fft_groups(S, groups(), false)) s2c_.emplace_back(ckks, std::move(g), S, lvl++);
     }
-    PhantomCiphertext eval_mod(const PhantomCiphertext &w) {
-        PhantomCiphertext c = cheb_(w, delta_);
-        for (long i = 0; i < scale_factor; i++) c = ckks->square_double_minus_one(c);
+    PhantomCiphertext eval_mod(CKKSEvaluator &ev, ChebyshevEvaluator &cheb, const PhantomCiphertext &w) {
+        PhantomCiphertext c = cheb(w, delta_);
+        for (long i = 0; i < scale_factor; i++) c = ev.square_double_minus_one(c);
         return c;
     }
 
@@ -650,9 +684,9 @@ public:
     void prepare_mod_polynomial() {
         Kb_ = static_cast<double>(boundary_K) + 0.5;
         const double Kb = Kb_, rr = std::exp2(static_cast<double>(scale_factor)), kPi = 3.14159265358979323846;
-        cheb_ = ChebyshevEvaluator(ckks, ChebyshevEvaluator::interpolate(
-                                             [=](double w) { return std::cos(2.0 * kPi * (Kb * w - 0.25) / rr); },
-                                             static_cast<int>(sin_cos_deg)));
+        cheb_coeffs_ = ChebyshevEvaluator::interpolate([=](double w) { return std::cos(2.0 * kPi * (Kb * w - 0.25) / rr); },
+                                                       static_cast<int>(sin_cos_deg));
+        cheb_ = ChebyshevEvaluator(ckks, cheb_coeffs_);
         plan_levels();
         prepared_ = true;
     }
@@ -726,8 +760,18 @@ public:
         PhantomCiphertext cj = ckks->conj(t);
         PhantomCiphertext re = ckks->add(t, cj);
         PhantomCiphertext im = ckks->neg(ckks->mul_i(ckks->sub(t, cj)));
-        PhantomCiphertext v = eval_mod(re);  // 2 pi m / q0 on both parts
-        PhantomCiphertext vi = ckks->mul_i(eval_mod(im));
+        // 2 pi m / q0 on both parts: two independent EvalMods, side by side on the sibling (context, stream) pair
+        PhantomCiphertext v, vi;
+        if (concurrent_evalmod) {
+            cheb_sibling_ = ChebyshevEvaluator(&ckks->sibling(), cheb_coeffs_);
+            auto pair = ckks->run_pair([&](CKKSEvaluator &ev) { return eval_mod(ev, cheb_, re); },
+                                       [&](CKKSEvaluator &ev) { return eval_mod(ev, cheb_sibling_, im); });
+            v = std::move(pair.first);
+            vi = ckks->mul_i(pair.second);
+        } else {
+            v = eval_mod(*ckks, cheb_, re);
+            vi = ckks->mul_i(eval_mod(*ckks, cheb_, im));
+        }
         ckks->add_inplace(v, vi);
         for (auto &lt : s2c_) v = lt.apply(v);
         v.set_scale(v.scale() * in_scale / final_scale);  // src/boot/Bootstrapper.cu:2933 (a ratio of ~1)
