@@ -293,6 +293,12 @@ int pha_rotate_hoisted(pha_context *ctx, size_t chain_index, const uint64_t *ct,
                        const uint32_t *galois_elts_host, const uint64_t *const *const *evks_host,
                        uint64_t *const *out_host, pha_stream_t stream);
 
+/* apply_galois_inplace (src/evaluate.cu:747-794) on `batch` independent ciphertexts sharing the Galois element and
+ * its key: in / out are [batch][2][l][N] contiguous, out of place (BASELINE configs[3], rotate x 64).  Results are
+ * bit-identical to `batch` calls of pha_apply_galois_inplace; the reference has no batched entry point. */
+int pha_apply_galois_batched(pha_context *ctx, size_t chain_index, const uint64_t *in, uint64_t *out, size_t batch,
+                             uint32_t galois_elt, const uint64_t *const *galois_evks, pha_stream_t stream);
+
 /* Plaintext over Q_l u P ([size_Ql + size_P][N], NTT form): pha_ckks_encode with the special primes appended, the
  * operand format of pha_linear_transform_double_hoisted.  No counterpart in the reference. */
 int pha_ckks_encode_qp(pha_context *ctx, const double *values_host, size_t values_size, size_t sparse_slots,

@@ -93,6 +93,7 @@ SIGNATURES = {
     "pha_ckks_encode": (_int, [_vp, _vp, _sz, _sz, _sz, ctypes.c_double, _vp, _vp]),
     "pha_ckks_decode": (_int, [_vp, _vp, _sz, ctypes.c_double, _sz, _vp, _vp]),
     "pha_rotate_hoisted": (_int, [_vp, _sz, _vp, _sz, _u32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
+    "pha_apply_galois_batched": (_int, [_vp, _sz, _vp, _vp, _sz, _u32, _vp, _vp]),
     "pha_ckks_encode_qp": (_int, [_vp, _vp, _sz, _sz, _sz, ctypes.c_double, _vp, _vp]),
     "pha_linear_transform_double_hoisted": (_int, [_vp, _sz, _vp, _sz, _u32p, ctypes.POINTER(_vp), _sz, _u32p, ctypes.POINTER(_vp),
                                                    ctypes.POINTER(_vp), _vp, _vp]),
@@ -483,6 +484,14 @@ class PhantomContext:
         out_ptrs = (_vp * len(outs))(*[o.data_ptr() for o in outs])
         _check(lib().pha_rotate_hoisted(self._h, chain_index, _ptr(ct), len(outs), elts, keys, out_ptrs, _stream()))
         return outs
+
+    def apply_galois_batched(self, chain_index, cts, galois_elt, galois_key):
+        """cts [batch][2][l][N] -> rotated copies, one launch sequence for the whole batch"""
+        import torch
+        out = torch.empty_like(cts)
+        _check(lib().pha_apply_galois_batched(self._h, chain_index, _ptr(cts), _ptr(out), cts.shape[0], galois_elt, galois_key.ptr,
+                                              _stream()))
+        return out
 
     def linear_transform_double_hoisted(self, chain_index, ct, baby_elts, baby_keys, giant_elts, giant_keys, plains):
         """sum_g rot_G( sum_b plains[g][b] * rot_B(ct) ) with one modup for the babies and one moddown per giant step

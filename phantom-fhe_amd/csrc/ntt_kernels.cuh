@@ -57,6 +57,8 @@ struct LimbMap {
     uint32_t digit_limit;           //      [p*alpha, min((p+1)*alpha, digit_limit))  (src/rns_bconv.cu:616-620)
     uint32_t tidx_bias;             // size_P == 0: table index = buffer limb + tidx_bias (a window of the P limbs of
                                     // a Q_l u P buffer in the limb-parallel key switch)
+    uint32_t digit_count;           // > 0 with digit_alpha: buffers are [batch][digit_count] and poly p is digit
+                                    // p % digit_count (batched key switch)
 };
 
 struct NttTables {
@@ -79,6 +81,8 @@ struct Epilogue {
     const uint64_t *addend;
     const uint64_t *cst, *cst_shoup;  // indexed by absolute buffer limb
     size_t out_poly_stride, sub_poly_stride;
+    uint32_t addend_every;  // > 0: only polys p with p % addend_every == 0 take the addend (a rotation adds pi(c0) to
+                            // the first poly of each ciphertext and nothing to the second)
 };
 
 enum : int { EPI_NONE = 0, EPI_SUB_MUL = 1, EPI_SUB_MUL_ADD = 2, EPI_SCALE = 3 };
@@ -120,7 +124,7 @@ __device__ unsigned long long *pha_trace_buf;
 __device__ __forceinline__ bool resolve_limb(const LimbMap &m, uint32_t poly, uint32_t li, uint32_t &twr, uint32_t &tidx) {
     uint32_t es = m.excl_start, ee = m.excl_end;
     if (m.digit_alpha) {
-        es = poly * m.digit_alpha;
+        es = (m.digit_count ? poly % m.digit_count : poly) * m.digit_alpha;
         ee = min(es + m.digit_alpha, m.digit_limit);
     }
     // only the part of the skipped range that lies inside this launch's window counts
@@ -366,7 +370,7 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, uint64_t *base, con
             const ulonglong2 s = *reinterpret_cast<const ulonglong2 *>(sub + e);
             v.x = f.to_u64(f.sub_mul(v0, s.x, c));
             v.y = f.to_u64(f.sub_mul(v1, s.y, c));
-            if (EPI == EPI_SUB_MUL_ADD) {
+            if (EPI == EPI_SUB_MUL_ADD && addend != nullptr) {
                 const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(addend + e);
                 v.x = csub(v.x + a.x, q);
                 v.y = csub(v.y + a.y, q);
@@ -401,7 +405,8 @@ __global__ PHA_NTT_BOUNDS void fntt_row_kernel(uint64_t *data, size_t poly_strid
     if (EPI != EPI_NONE) {
         out = ep.out + poly * ep.out_poly_stride + limb_off;
         sub = ep.sub + poly * ep.sub_poly_stride + limb_off;
-        if (EPI == EPI_SUB_MUL_ADD) addend = ep.addend + poly * ep.out_poly_stride + limb_off;
+        if (EPI == EPI_SUB_MUL_ADD && (ep.addend_every == 0 || poly % ep.addend_every == 0))
+            addend = ep.addend + poly * ep.out_poly_stride + limb_off;
         cst = ep.cst[twr];
         cst_shoup = ep.cst_shoup[twr];
     }

@@ -257,7 +257,7 @@ int make_range(const pha_context *ctx, size_t count, size_t start, size_t size_Q
     r.active = static_cast<uint32_t>(count) - len;
     r.lm = LimbMap{static_cast<uint32_t>(start), static_cast<uint32_t>(count), static_cast<uint32_t>(size_QP),
                    static_cast<uint32_t>(size_P), static_cast<uint32_t>(excl_s), static_cast<uint32_t>(excl_e),
-                   r.active, 1u, 0u, 0u, 0u};
+                   r.active, 1u, 0u, 0u, 0u, 0u};
     return PHA_OK;
 }
 
@@ -462,14 +462,14 @@ int do_modup(pha_context *ctx, LevelTool *lt, uint64_t *dst, const uint64_t *cks
         if (lt->uniform_digits) {
             const uint32_t obase = static_cast<uint32_t>(size_QlP - alpha);
             BconvBatch bt{size_QlP * n, alpha * n, static_cast<size_t>(obase) * alpha, obase,
-                          static_cast<uint32_t>(alpha), cks, alpha * n};
+                          static_cast<uint32_t>(alpha), cks, alpha * n, 0, 0, 0};
             PHA_TRY(launch_bconv(ctx, dst, t_cks, lt->modup_matrix_all.p, lt->modup_tidx_all.p,
                                  static_cast<uint32_t>(alpha), obase, 0, static_cast<uint32_t>(alpha),
                                  static_cast<uint32_t>(lt->beta), bt, st));
         } else {
             for (size_t d = 0; d < lt->beta; d++) {
                 const size_t s = d * alpha, e = std::min(s + alpha, size_Ql), len = e - s;
-                BconvBatch bt{0, 0, 0, 0, 0, cks + s * n, 0};
+                BconvBatch bt{0, 0, 0, 0, 0, cks + s * n, 0, 0, 0, 0};
                 PHA_TRY(launch_bconv(ctx, dst + d * size_QlP * n, t_cks + s * n, lt->modup_matrix[d].p,
                                      lt->modup_obase_tidx[d].p, static_cast<uint32_t>(len),
                                      static_cast<uint32_t>(size_QlP - len), static_cast<uint32_t>(s),
@@ -498,11 +498,49 @@ int do_inner_prod(pha_context *ctx, LevelTool *lt, uint64_t *cx, const uint64_t 
     return check_launch("key_switch_inner_prod");
 }
 
+// modup of `batch` ciphertexts' c2 at once (uniform digits, alpha > 1): cks / t_cks hold the b-th polynomial at
+// b * in_stride, dst is [batch][beta][size_QlP][n]
+int do_modup_batched(pha_context *ctx, LevelTool *lt, uint64_t *dst, const uint64_t *cks, uint64_t *t_cks, size_t in_stride,
+                     size_t batch, hipStream_t st) {
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, alpha = ctx->size_P, size_QlP = size_Ql + alpha;
+    NttRange r;
+    PHA_TRY(make_range(ctx, size_Ql, 0, 0, 0, 0, 0, r));
+    Epilogue ep{};
+    ep.cst = lt->partHatInv.v.p;
+    ep.cst_shoup = lt->partHatInv.s.p;
+    PHA_TRY(ntt_backward(ctx, t_cks, cks, batch, in_stride, r, EPI_SCALE, ep, st));
+    const uint32_t obase = static_cast<uint32_t>(size_QlP - alpha);
+    BconvBatch bt{size_QlP * n, alpha * n, static_cast<size_t>(obase) * alpha, obase, static_cast<uint32_t>(alpha), cks, alpha * n,
+                  static_cast<uint32_t>(lt->beta), in_stride, in_stride};
+    PHA_TRY(launch_bconv(ctx, dst, t_cks, lt->modup_matrix_all.p, lt->modup_tidx_all.p, static_cast<uint32_t>(alpha), obase, 0,
+                         static_cast<uint32_t>(alpha), static_cast<uint32_t>(lt->beta * batch), bt, st));
+    NttRange rr;
+    PHA_TRY(make_range(ctx, size_QlP, 0, ctx->size_QP, alpha, 0, 0, rr));
+    rr.lm.digit_alpha = static_cast<uint32_t>(alpha);
+    rr.lm.digit_limit = static_cast<uint32_t>(size_Ql);
+    rr.lm.digit_count = static_cast<uint32_t>(lt->beta);
+    rr.active = rr.lm.active = static_cast<uint32_t>(size_QlP - alpha);
+    return ntt_forward(ctx, dst, lt->beta * batch, size_QlP * n, rr, EPI_NONE, Epilogue{}, st);
+}
+
+int do_inner_prod_batched(pha_context *ctx, LevelTool *lt, uint64_t *cx, const uint64_t *t_mod_up, const uint64_t *const *evks,
+                          size_t batch, hipStream_t st) {
+    constexpr int BPW = 4;
+    const uint32_t n = static_cast<uint32_t>(ctx->n);
+    const uint32_t size_QlP = static_cast<uint32_t>(lt->size_Ql + ctx->size_P);
+    const uint32_t groups = static_cast<uint32_t>((batch + BPW - 1) / BPW);
+    hipLaunchKernelGGL((key_switch_inner_prod_batched_kernel<BPW>), dim3(size_QlP * (n / 512) * groups), dim3(256), 0, st, cx,
+                       t_mod_up, evks, ctx->d_mod.p, n, static_cast<uint32_t>(ctx->size_QP), size_QlP,
+                       static_cast<uint32_t>(ctx->size_Q), static_cast<uint32_t>(lt->size_Ql), static_cast<uint32_t>(lt->beta),
+                       static_cast<uint32_t>(batch));
+    return check_launch("key_switch_inner_prod_batched");
+}
+
 // DRNSTool::moddown_from_NTT (src/rns_bconv.cu:776-828) for `polys` buffers at once
 // (cx stride size_QlP*n, ct stride size_Ql*n), delta = scratch [polys][size_Ql][n].
 // addend != nullptr fuses add_to_ct: ct = addend + (cx - NTT(delta)) * PInv
 int do_moddown(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *cx, uint64_t *delta, const uint64_t *addend,
-               size_t polys, hipStream_t st) {
+               size_t polys, hipStream_t st, uint32_t addend_every = 0) {
     const size_t n = ctx->n, size_Ql = lt->size_Ql, alpha = ctx->size_P, size_QlP = size_Ql + alpha;
     NttRange rp;
     PHA_TRY(make_range(ctx, alpha, size_Ql, ctx->size_QP, alpha, 0, 0, rp));
@@ -519,7 +557,7 @@ int do_moddown(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *cx, uint
         ep.cst = lt->PHatInv.v.p - size_Ql;
         ep.cst_shoup = lt->PHatInv.s.p - size_Ql;
         PHA_TRY(ntt_backward(ctx, cx, cx, polys, size_QlP * n, rp, EPI_SCALE, ep, st));
-        BconvBatch bt{size_Ql * n, size_QlP * n, 0, 0, 0, nullptr, 0};
+        BconvBatch bt{size_Ql * n, size_QlP * n, 0, 0, 0, nullptr, 0, 0, 0, 0};
         PHA_TRY(launch_bconv(ctx, delta, cp, lt->moddown_matrix.p, lt->moddown_obase_tidx.p, static_cast<uint32_t>(alpha),
                              static_cast<uint32_t>(size_Ql), static_cast<uint32_t>(size_Ql), 0,
                              static_cast<uint32_t>(polys), bt, st));
@@ -530,6 +568,7 @@ int do_moddown(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *cx, uint
     ep.out = ct;
     ep.sub = cx;
     ep.addend = addend;
+    ep.addend_every = addend_every;
     ep.cst = lt->bigPInv.v.p;
     ep.cst_shoup = lt->bigPInv.s.p;
     ep.out_poly_stride = size_Ql * n;
@@ -537,8 +576,9 @@ int do_moddown(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *cx, uint
     return ntt_forward(ctx, delta, polys, size_Ql * n, rq, addend ? EPI_SUB_MUL_ADD : EPI_SUB_MUL, ep, st);
 }
 
+// addend (default ct itself) is what the switched key part is added to; addend_every as in Epilogue
 int do_keyswitch(pha_context *ctx, LevelTool *lt, uint64_t *ct, const uint64_t *c2, const uint64_t *const *evks,
-                 hipStream_t st) {
+                 hipStream_t st, const uint64_t *addend = nullptr, uint32_t addend_every = 0) {
     const size_t n = ctx->n, size_Ql = lt->size_Ql, size_QlP = size_Ql + ctx->size_P;
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n, &ws));
@@ -547,7 +587,7 @@ int do_keyswitch(pha_context *ctx, LevelTool *lt, uint64_t *ct, const uint64_t *
     PHA_TRY(do_inner_prod(ctx, lt, cx, t_mod_up, evks, st));
     // both polys' moddown in one launch sequence, add_to_ct fused into the NTT epilogue
     // (src/eval_key_switch.cu:157-177)
-    return do_moddown(ctx, lt, ct, cx, scratch, ct, 2, st);
+    return do_moddown(ctx, lt, ct, cx, scratch, addend ? addend : ct, 2, st, addend_every);
 }
 
 int do_rescale(pha_context *ctx, LevelTool *lt, const uint64_t *src, const uint64_t *last_coeff, size_t last_stride,
@@ -692,7 +732,7 @@ int lp_moddown_finish(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *c
                            static_cast<uint32_t>(n), size_Ql * n, size_QlP * n);
         PHA_TRY(check_launch("reduce_single_limb"));
     } else {
-        BconvBatch bt{size_Ql * n, size_QlP * n, 0, 0, 0, nullptr, 0};
+        BconvBatch bt{size_Ql * n, size_QlP * n, 0, 0, 0, nullptr, 0, 0, 0, 0};
         PHA_TRY(launch_bconv(ctx, delta + w.q0 * n, cp, lt->moddown_matrix.p + w.q0 * alpha, lt->moddown_obase_tidx.p + w.q0,
                              static_cast<uint32_t>(alpha), static_cast<uint32_t>(w.qc), static_cast<uint32_t>(w.qc), 0, 2,
                              bt, st));
@@ -1251,11 +1291,10 @@ int pha_apply_galois_inplace(pha_context *ctx, size_t chain_index, uint64_t *ct,
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, ks_words + 2 * size_Ql * n, &ws));
     uint64_t *temp = ws + ks_words;
-    // c0 <- galois(c0); temp1 <- galois(c1); c1 <- 0; ct += KS(temp1)   (src/evaluate.cu:774-793)
+    // c0 <- galois(c0); temp1 <- galois(c1); c1 <- 0; ct += KS(temp1)   (src/evaluate.cu:774-793): the moddown
+    // epilogue writes ct = (galois(c0), 0) + KS directly — no copy of galois(c0), no memset of c1
     PHA_TRY(do_galois(ctx, ct, 2 * size_Ql, perm, temp, st));
-    HIP_TRY(hipMemcpyAsync(ct, temp, size_Ql * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemsetAsync(ct + size_Ql * n, 0, size_Ql * n * sizeof(uint64_t), st));
-    return do_keyswitch(ctx, lt, ct, temp + size_Ql * n, galois_evks, st);
+    return do_keyswitch(ctx, lt, ct, temp + size_Ql * n, galois_evks, st, temp, 2);
 }
 
 int pha_rescale_to_next(pha_context *ctx, size_t chain_index, const uint64_t *src, size_t cipher_size, uint64_t *dst,
@@ -1640,8 +1679,7 @@ int pha_rotate_hoisted(pha_context *ctx, size_t chain_index, const uint64_t *ct,
         PHA_TRY(get_galois_table(ctx, galois_elts_host[r], &perm));
         PHA_TRY(do_inner_prod(ctx, lt, cx, t_mod_up, evks_host[r], st, perm));
         PHA_TRY(do_galois(ctx, ct, size_Ql, perm, out_host[r], st));
-        HIP_TRY(hipMemsetAsync(out_host[r] + size_Ql * n, 0, size_Ql * n * sizeof(uint64_t), st));
-        PHA_TRY(do_moddown(ctx, lt, out_host[r], cx, scratch, out_host[r], 2, st));
+        PHA_TRY(do_moddown(ctx, lt, out_host[r], cx, scratch, out_host[r], 2, st, 2));  // poly 0 += pi(c0), poly 1 as is
     }
     return PHA_OK;
 }
@@ -1732,6 +1770,45 @@ int pha_linear_transform_double_hoisted(pha_context *ctx, size_t chain_index, co
     }
     if (first) return fail(PHA_ERR_INVALID_ARGUMENT, "the transform has no plaintext");
     return do_moddown(ctx, lt, out, total, scratch, nullptr, 2, st);
+}
+
+// apply_galois_inplace on `batch` independent ciphertexts that share the Galois element and its key
+// (BASELINE configs[3]: rotate x 64).  Every step is one launch over the whole batch: larger grids run the NTT
+// kernels in their steady state and the ciphertexts of a batch read each key tile together.
+int pha_apply_galois_batched(pha_context *ctx, size_t chain_index, const uint64_t *in, uint64_t *out, size_t batch,
+                             uint32_t galois_elt, const uint64_t *const *galois_evks, pha_stream_t stream) {
+    REQUIRE_CTX(in && out && galois_evks);
+    if (batch == 0) return PHA_OK;
+    if (in == out) return fail(PHA_ERR_INVALID_ARGUMENT, "the batched rotation is out of place");
+    LevelTool *lt;
+    PHA_TRY(get_level(ctx, chain_index, &lt));
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, size_QlP = size_Ql + ctx->size_P, ct_words = 2 * size_Ql * n;
+    hipStream_t st = as_stream(stream);
+    const uint32_t *perm;
+    PHA_TRY(get_galois_table(ctx, galois_elt, &perm));
+    if (!lt->uniform_digits) {  // alpha == 1 or a ragged last digit: one ciphertext at a time
+        for (size_t b = 0; b < batch; b++) {
+            PHA_TRY(do_galois(ctx, in + b * ct_words, 2 * size_Ql, perm, out + b * ct_words, st));
+            uint64_t *ws;
+            PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 3 * size_Ql) * n, &ws));
+            uint64_t *c2 = ws + (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n;
+            HIP_TRY(hipMemcpyAsync(c2, out + b * ct_words + size_Ql * n, size_Ql * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemsetAsync(out + b * ct_words + size_Ql * n, 0, size_Ql * n * sizeof(uint64_t), st));
+            PHA_TRY(do_keyswitch(ctx, lt, out + b * ct_words, c2, galois_evks, st));
+        }
+        return PHA_OK;
+    }
+    // workspace: t_mod_up [batch][beta][QlP] | cx [batch][2][QlP] | t_cks [batch][2][Ql] (poly 1 slots used) | delta [2 batch][Ql]
+    uint64_t *ws;
+    PHA_TRY(ensure_workspace(ctx, batch * (lt->beta * size_QlP + 2 * size_QlP + 4 * size_Ql) * n, &ws));
+    uint64_t *t_mod_up = ws, *cx = t_mod_up + batch * lt->beta * size_QlP * n, *t_cks = cx + batch * 2 * size_QlP * n,
+             *delta = t_cks + batch * ct_words;
+    // permute both polys of every ciphertext (src/evaluate.cu:747-794)
+    PHA_TRY(do_galois(ctx, in, batch * 2 * size_Ql, perm, out, st));
+    // key switch the permuted c1 of every ciphertext
+    PHA_TRY(do_modup_batched(ctx, lt, t_mod_up, out + size_Ql * n, t_cks + size_Ql * n, ct_words, batch, st));
+    PHA_TRY(do_inner_prod_batched(ctx, lt, cx, t_mod_up, galois_evks, batch, st));
+    return do_moddown(ctx, lt, out, cx, delta, out, 2 * batch, st, 2);  // first polys += pi(c0), second polys as they come
 }
 
 // ---- bootstrapping primitives (src/boot/Bootstrapper.cu) ------------------------------------------

@@ -21,7 +21,24 @@ struct BconvBatch {
     uint32_t skip_stride;
     const uint64_t *copy_src;  // optional: the digit's own (NTT-form) limbs, copied to the skipped slots
     size_t copy_stride;        // (src/rns_bconv.cu:522-528 modup_copy_partQl_kernel, fused)
+    // group > 0: z = b * group + d runs over [batch of ciphertexts][digits]; the per-digit strides above apply to d,
+    // the group strides to b (dst stays linear in z)
+    uint32_t group;
+    size_t y_group_stride, copy_group_stride;
 };
+
+__device__ __forceinline__ void bconv_batch_offsets(const BconvBatch &bt, uint32_t z, uint64_t *__restrict__ &dst,
+                                                    const uint64_t *__restrict__ &y, const uint64_t *__restrict__ &matrix,
+                                                    const uint32_t *__restrict__ &obase_tidx, uint32_t &skip_start,
+                                                    const uint64_t *&copy_src) {
+    const uint32_t d = bt.group ? z % bt.group : z, b = bt.group ? z / bt.group : 0;
+    dst += z * bt.dst_stride;
+    y += d * bt.y_stride + b * bt.y_group_stride;
+    matrix += d * bt.matrix_stride;
+    obase_tidx += d * bt.tidx_stride;
+    skip_start += d * bt.skip_stride;
+    copy_src = bt.copy_src ? bt.copy_src + d * bt.copy_stride + b * bt.copy_group_stride : nullptr;
+}
 
 // 128-bit dot product by columns: every input and matrix entry is a residue < 2^61, so the high
 // words are < 2^29.  c0 collects the low x low products with an explicit carry counter (the
@@ -58,17 +75,12 @@ __global__ __launch_bounds__(256) void bconv_matmul_kernel(uint64_t *__restrict_
                                                            uint32_t obase_size, uint32_t limbs_per_block, uint32_t n,
                                                            uint32_t skip_start, uint32_t skip_len, BconvBatch bt) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t z = blockIdx.z;
-    dst += z * bt.dst_stride;
-    y += z * bt.y_stride;
-    matrix += z * bt.matrix_stride;
-    obase_tidx += z * bt.tidx_stride;
-    skip_start += z * bt.skip_stride;
+    const uint64_t *src;
+    bconv_batch_offsets(bt, blockIdx.z, dst, y, matrix, obase_tidx, skip_start, src);
     uint64_t in[IB];
 #pragma unroll
     for (int i = 0; i < IB; i++) in[i] = y[static_cast<size_t>(i) * n + k];
-    if (bt.copy_src != nullptr && blockIdx.y == 0) {
-        const uint64_t *src = bt.copy_src + z * bt.copy_stride;
+    if (src != nullptr && blockIdx.y == 0) {
 #pragma unroll
         for (int i = 0; i < IB; i++) dst[static_cast<size_t>(skip_start + i) * n + k] = src[static_cast<size_t>(i) * n + k];
     }
@@ -90,14 +102,9 @@ __global__ __launch_bounds__(256) void bconv_matmul_generic_kernel(uint64_t *dst
                                                                    uint32_t n, uint32_t skip_start, uint32_t skip_len,
                                                                    BconvBatch bt) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t z = blockIdx.z;
-    dst += z * bt.dst_stride;
-    y += z * bt.y_stride;
-    matrix += z * bt.matrix_stride;
-    obase_tidx += z * bt.tidx_stride;
-    skip_start += z * bt.skip_stride;
-    if (bt.copy_src != nullptr && blockIdx.y == 0) {
-        const uint64_t *src = bt.copy_src + z * bt.copy_stride;
+    const uint64_t *src;
+    bconv_batch_offsets(bt, blockIdx.z, dst, y, matrix, obase_tidx, skip_start, src);
+    if (src != nullptr && blockIdx.y == 0) {
         for (uint32_t i = 0; i < ibase_size; i++)
             dst[static_cast<size_t>(skip_start + i) * n + k] = src[static_cast<size_t>(i) * n + k];
     }
@@ -196,6 +203,53 @@ __global__ __launch_bounds__(256) void key_switch_inner_prod_kernel(uint64_t *ds
     r1.y = barrett128(a1y, m);
     *reinterpret_cast<ulonglong2 *>(dst + c2_id) = r0;
     *reinterpret_cast<ulonglong2 *>(dst + size_QlP_n + c2_id) = r1;
+}
+
+// The same inner product for a batch of ciphertexts that share the key (pha_apply_galois_batched): a workgroup
+// takes BPW ciphertexts of one (limb, tile) and reads every key word once for all of them — the key is the largest
+// operand (144 MiB at configs[2] against 72 MiB of t_mod_up per ciphertext).  t_mod_up [batch][beta][size_QlP][n],
+// dst [batch][2][size_QlP][n]; gridDim.x = size_QlP * (n / 512) * ceil(batch / BPW).
+template <int BPW>
+__global__ __launch_bounds__(256) void key_switch_inner_prod_batched_kernel(uint64_t *dst, const uint64_t *t_mod_up,
+                                                                            const uint64_t *const *evks, const DModulus *mod,
+                                                                            uint32_t n, uint32_t size_QP, uint32_t size_QlP,
+                                                                            uint32_t size_Q, uint32_t size_Ql, uint32_t beta,
+                                                                            uint32_t batch) {
+    const uint32_t per_limb = n / 512, groups = (batch + BPW - 1) / BPW;
+    const uint32_t bx = blockIdx.x / groups, b0 = (blockIdx.x % groups) * BPW;
+    const uint32_t nid = bx / per_limb;
+    const uint32_t k = ((bx % per_limb) * 256 + threadIdx.x) * 2;
+    const uint32_t twr = nid >= size_Ql ? size_Q + (nid - size_Ql) : nid;
+    const DModulus m = mod[twr];
+    const size_t c2_id = static_cast<size_t>(nid) * n + k;
+    const size_t evk_id = static_cast<size_t>(twr) * n + k;
+    const size_t size_QlP_n = static_cast<size_t>(size_QlP) * n, size_QP_n = static_cast<size_t>(size_QP) * n;
+    u128_t acc[BPW][4];
+#pragma unroll
+    for (int b = 0; b < BPW; b++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[b][i] = u128_t{0, 0};
+    for (uint32_t d = 0; d < beta; d++) {
+        const uint64_t *evk = evks[d];
+        const ulonglong2 e0 = *reinterpret_cast<const ulonglong2 *>(evk + evk_id);
+        const ulonglong2 e1 = *reinterpret_cast<const ulonglong2 *>(evk + size_QP_n + evk_id);
+#pragma unroll
+        for (int b = 0; b < BPW; b++) {
+            if (b0 + b >= batch) break;
+            const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(t_mod_up + (static_cast<size_t>(b0 + b) * beta + d) * size_QlP_n + c2_id);
+            add128(acc[b][0], mul64x64(t.x, e0.x));
+            add128(acc[b][1], mul64x64(t.y, e0.y));
+            add128(acc[b][2], mul64x64(t.x, e1.x));
+            add128(acc[b][3], mul64x64(t.y, e1.y));
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < BPW; b++) {
+        if (b0 + b >= batch) break;
+        uint64_t *o = dst + static_cast<size_t>(b0 + b) * 2 * size_QlP_n + c2_id;
+        *reinterpret_cast<ulonglong2 *>(o) = ulonglong2{barrett128(acc[b][0], m), barrett128(acc[b][1], m)};
+        *reinterpret_cast<ulonglong2 *>(o + size_QlP_n) = ulonglong2{barrett128(acc[b][2], m), barrett128(acc[b][3], m)};
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

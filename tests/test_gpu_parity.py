@@ -289,6 +289,31 @@ def test_double_hoisted_linear_transform(gpu, pha, orc, size_p, chain_index):
     ctx.close()
 
 
+@pytest.mark.parametrize("size_p,chain_index,batch", [(2, 1, 5), (2, 2, 3), (3, 1, 4), (1, 1, 3), (3, 3, 2)])
+def test_batched_rotation_equals_one_by_one(gpu, pha, orc, size_p, chain_index, batch):
+    """pha_apply_galois_batched = `batch` x pha_apply_galois_inplace, bit for bit (and so the oracle's result):
+    uniform digits take the batched kernels, alpha = 1 and a ragged last digit the per-ciphertext path."""
+    import torch
+    mods = orc.coeff_modulus_create(4096, [45] * 6 + [55] * size_p)
+    ctx, o = pha.PhantomContext(12, mods, size_p), orc.Oracle(12, mods, size_p)
+    size_ql = ctx.size_Ql(chain_index)
+    evk_h, evk_d = _uniform_evk(pha, o, 900)
+    cts = np.stack([np.stack([o.uniform_poly(list(range(size_ql)), 910 + 2 * b), o.uniform_poly(list(range(size_ql)), 911 + 2 * b)])
+                    for b in range(batch)])
+    elt = pha.galois_elt_from_step(12, 3)
+    d_in = _dev(pha, cts)
+    out = ctx.apply_galois_batched(chain_index, d_in, elt, evk_d)
+    assert (_host(pha, d_in) == cts).all()
+    for b in range(batch):
+        one = _dev(pha, cts[b])
+        ctx.apply_galois_inplace(chain_index, one, elt, evk_d)
+        assert torch.equal(out[b], one)
+    ref = np.stack([o.apply_galois_ntt(cts[0][0], elt), np.zeros_like(cts[0][1])])
+    o.keyswitch_inplace(size_ql, ref, o.apply_galois_ntt(cts[0][1], elt), evk_h)
+    assert (_host(pha, out[0]) == ref).all()
+    ctx.close()
+
+
 def test_bad_chain_index(gpu, pha, small):
     ctx, o = small
     import torch

@@ -36,7 +36,17 @@ def main():
                        for _ in range(SIZE_Q // SIZE_P)])
     elt = pha.galois_elt_from_step(16, 1)
 
+    # BATCH > 1: the rank's ciphertexts go through pha_apply_galois_batched in groups of BATCH (one launch sequence
+    # per group; every kernel spans the group)
+    batch = int(os.environ.get("BATCH", "16"))
+    groups = [torch.stack(cts[i:i + batch]) for i in range(0, len(cts), batch)] if batch > 1 else []
+
     def step():
+        if batch > 1:
+            for i, grp in enumerate(groups):
+                with torch.cuda.stream(streams[i % n_streams]):
+                    ctxs[i % n_streams].apply_galois_batched(1, grp, elt, evk)
+            return
         for i, ct in enumerate(cts):
             with torch.cuda.stream(streams[i % n_streams]):
                 ctxs[i % n_streams].apply_galois_inplace(1, ct, elt, evk)
@@ -57,7 +67,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "CKKS rotate, 64 independent ciphertexts (N=2^16, 36+12 limbs, dnum=3)",
                           "value": TOTAL * steps / el, "unit": "ciphertexts/s", "ms_per_64": 1e3 * el / steps,
-                          "n_gpus": world, "steps": steps, "streams": n_streams, "scaling": "strong", "data": "synthetic"}), flush=True)
+                          "n_gpus": world, "steps": steps, "streams": n_streams, "batch": batch, "scaling": "strong", "data": "synthetic"}), flush=True)
     for c in ctxs:
         c.close()
     if dist is not None:
