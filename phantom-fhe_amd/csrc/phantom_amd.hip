@@ -421,8 +421,16 @@ int launch_bconv(pha_context *ctx, uint64_t *dst, const uint64_t *y, const uint6
                  uint32_t ibase, uint32_t obase, uint32_t skip_start, uint32_t skip_len, uint32_t batch,
                  const BconvBatch &bt, hipStream_t st) {
     const uint32_t n = static_cast<uint32_t>(ctx->n);
-    // enough workgroups to fill 256 CUs a few times over without re-reading the inputs too often
-    uint32_t lpb = std::max<uint32_t>(1, obase / 8);
+    // Every output-limb group re-reads the ibase input limbs: as few groups as still give ~4096 workgroups
+    // (measured at configs[2]: targets 512..9216 give HMult 0.343 / 0.331 / 0.332 / 0.327 / 0.336 ms; a batch of 16
+    // rotations needs one group and gains 2.5 %); PHA_BCONV_WGS overrides the target for experiments.
+    static const uint32_t target = [] {
+        const char *e = getenv("PHA_BCONV_WGS");
+        return e ? static_cast<uint32_t>(atoi(e)) : 4096u;
+    }();
+    const uint32_t base_wgs = (n / 256) * batch;
+    const uint32_t groups = std::min<uint32_t>(obase, std::max<uint32_t>(1, (target + base_wgs - 1) / base_wgs));
+    const uint32_t lpb = (obase + groups - 1) / groups;
     const dim3 grid(n / 256, (obase + lpb - 1) / lpb, batch);
     const DModulus *mod = ctx->d_mod.p;
 #define BCONV_CASE(IB)                                                                                          \
