@@ -53,6 +53,13 @@ public:
     const hipStream_t &get_stream() const { return stream_; }
 };
 
+// The reference's evaluator functions default their stream argument to one global stream created with the context
+// (phantom::util::global_variables::default_stream, src/context.cu:16-18,137); same here, created on first use.
+inline const hip_stream_wrapper &default_stream() {
+    static hip_stream_wrapper *s = new hip_stream_wrapper;  // never destroyed: the HIP runtime may be gone at exit
+    return *s;
+}
+
 // Stream-ordered recycling of temporaries (the role of the reference's cudaMallocAsync pool with an unlimited
 // release threshold, include/cuda_wrapper.cuh:141-186, src/context.cu:130-135): a buffer released on stream s is
 // handed to the next request of the same size on the SAME stream, whose work is enqueued after the previous
@@ -219,6 +226,19 @@ public:
     PhantomCiphertext() = default;
     PhantomCiphertext(PhantomCiphertext &&) = default;
     PhantomCiphertext &operator=(PhantomCiphertext &&) = default;
+    // Deep copies (the reference's `PhantomCiphertext destination = encrypted;`): correct from any stream — the
+    // device is synchronised first, the copy runs on the default stream and is complete on return.  Hot paths use
+    // clone(stream), which is stream-ordered and does not synchronise.
+    PhantomCiphertext(const PhantomCiphertext &o) { *this = o; }
+    PhantomCiphertext &operator=(const PhantomCiphertext &o) {
+        if (this != &o) {
+            check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize");
+            const hipStream_t &s = default_stream().get_stream();
+            *this = o.clone(s);
+            check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+        }
+        return *this;
+    }
 
     // reallocates and keeps the overlapping prefix, like ciphertext.h:56-86
     void resize(const PhantomContext &context, size_t chain_index, size_t size, const hipStream_t &stream) {
@@ -316,6 +336,24 @@ public:
     PhantomPlaintext() = default;
     PhantomPlaintext(PhantomPlaintext &&) = default;
     PhantomPlaintext &operator=(PhantomPlaintext &&) = default;
+    PhantomPlaintext(const PhantomPlaintext &o) { *this = o; }  // deep copy, synchronous (see PhantomCiphertext)
+    PhantomPlaintext &operator=(const PhantomPlaintext &o) {
+        if (this != &o) {
+            check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize");
+            data_ = device_words(o.data_.size());
+            if (o.data_.size())
+                check_hip(hipMemcpy(data_.get(), o.data_.get(), o.data_.size() * sizeof(uint64_t), hipMemcpyDeviceToDevice), "hipMemcpy");
+            chain_index_ = o.chain_index_, coeff_modulus_size_ = o.coeff_modulus_size_, poly_modulus_degree_ = o.poly_modulus_degree_;
+            scale_ = o.scale_;
+        }
+        return *this;
+    }
+    // CKKS mod_switch_to_next on a plaintext: drop the last limb (src/evaluate.cu:702-723)
+    void drop_last_limb() {
+        if (coeff_modulus_size_ < 2) throw std::invalid_argument("end of modulus switching chain reached");
+        coeff_modulus_size_ -= 1;  // limb-major layout: the remaining limbs are a prefix of the buffer
+        chain_index_ += 1;
+    }
     void resize(size_t coeff_modulus_size, size_t poly_modulus_degree, const hipStream_t &) {
         if (coeff_modulus_size * poly_modulus_degree != data_.size()) data_ = device_words(coeff_modulus_size * poly_modulus_degree);
         coeff_modulus_size_ = coeff_modulus_size, poly_modulus_degree_ = poly_modulus_degree;
@@ -339,7 +377,7 @@ public:
     // encode on an explicit slot count (a power of two <= N/2) without touching the encoder's own sparse_slots:
     // what the bootstrapper's diagonals and constants need
     void encode_slots(const PhantomContext &context, const std::vector<std::complex<double>> &values, size_t sparse_slots,
-                      double scale, PhantomPlaintext &destination, size_t chain_index, const hip_stream_wrapper &stream_wrapper) {
+                      double scale, PhantomPlaintext &destination, size_t chain_index, const hip_stream_wrapper &stream_wrapper = default_stream()) {
         const hipStream_t &s = stream_wrapper.get_stream();
         destination.resize(context.coeff_mod_size(chain_index), context.poly_degree(), s);
         check(pha_ckks_encode(context.handle(), reinterpret_cast<const double *>(values.data()), values.size(), sparse_slots,
@@ -353,7 +391,7 @@ public:
 
     // the first encode fixes sparse_slots (next power of two >= values.size()), like src/ckks.cu:150-158
     void encode(const PhantomContext &context, const std::vector<std::complex<double>> &values, double scale,
-                PhantomPlaintext &destination, size_t chain_index, const hip_stream_wrapper &stream_wrapper) {
+                PhantomPlaintext &destination, size_t chain_index, const hip_stream_wrapper &stream_wrapper = default_stream()) {
         if (values.size() > slots_) throw std::invalid_argument("values_size is too large");
         if (sparse_slots_ == 0)
             for (sparse_slots_ = 1; sparse_slots_ < values.size(); sparse_slots_ <<= 1) {}
@@ -365,12 +403,12 @@ public:
         destination.set_scale(scale);
     }
     void encode(const PhantomContext &context, const std::vector<double> &values, double scale, PhantomPlaintext &destination,
-                size_t chain_index, const hip_stream_wrapper &stream_wrapper) {
+                size_t chain_index, const hip_stream_wrapper &stream_wrapper = default_stream()) {
         std::vector<std::complex<double>> c(values.begin(), values.end());
         encode(context, c, scale, destination, chain_index, stream_wrapper);
     }
     void decode(const PhantomContext &context, const PhantomPlaintext &plain, std::vector<std::complex<double>> &destination,
-                const hip_stream_wrapper &stream_wrapper) {
+                const hip_stream_wrapper &stream_wrapper = default_stream()) {
         if (sparse_slots_ == 0) throw std::logic_error("decode before any encode: sparse_slots unknown");
         destination.resize(sparse_slots_);
         check(pha_ckks_decode(context.handle(), plain.data(), plain.chain_index(), plain.scale(), sparse_slots_,
@@ -391,7 +429,7 @@ public:
     uint64_t *data() const { return pk_.get(); }
     // src/secretkey.cu:133-164: fresh randomness per call (u, e0, e1), derived from the key's construction seed
     void encrypt_asymmetric(const PhantomContext &context, const PhantomPlaintext &plain, PhantomCiphertext &cipher,
-                            const hip_stream_wrapper &sw) {
+                            const hip_stream_wrapper &sw = default_stream()) {
         if (!pk_.get()) throw std::logic_error("public key has not been generated");
         const hipStream_t &s = sw.get_stream();
         cipher.resize(context, plain.chain_index(), 2, s);
@@ -455,11 +493,11 @@ public:
             check(pha_gen_secretkey(context.handle(), next_seed(), sk_.get(), stream));
         gen_flag_ = true;
     }
-    PhantomRelinKey gen_relinkey(const PhantomContext &context, const hip_stream_wrapper &sw) {
+    PhantomRelinKey gen_relinkey(const PhantomContext &context, const hip_stream_wrapper &sw = default_stream()) {
         return make_key(context, 0, 0, sw.get_stream());
     }
     // src/secretkey.cu:437-452
-    PhantomPublicKey gen_publickey(const PhantomContext &context, const hip_stream_wrapper &sw) {
+    PhantomPublicKey gen_publickey(const PhantomContext &context, const hip_stream_wrapper &sw = default_stream()) {
         PhantomPublicKey pk;
         pk.pk_ = device_words(2 * context.key_parms().coeff_modulus().size() * context.poly_degree());
         check(pha_gen_publickey(context.handle(), sk_.get(), next_seed(), pk.pk_.get(), sw.get_stream()));
@@ -467,7 +505,7 @@ public:
         return pk;
     }
     PhantomGaloisKey create_galois_keys_from_elts(const PhantomContext &context, const std::vector<uint32_t> &elts,
-                                                  const hip_stream_wrapper &sw) {
+                                                  const hip_stream_wrapper &sw = default_stream()) {
         PhantomGaloisKey gk;
         for (uint32_t e : elts) {
             if (!(e & 1) || e >= 2 * context.poly_degree()) throw std::invalid_argument("Galois element is not valid");
@@ -477,12 +515,12 @@ public:
     }
     // add the keys of `elts` that `gk` does not hold yet
     void add_galois_keys_from_elts(const PhantomContext &context, const std::vector<uint32_t> &elts, PhantomGaloisKey &gk,
-                                   const hip_stream_wrapper &sw) {
+                                   const hip_stream_wrapper &sw = default_stream()) {
         for (uint32_t e : elts)
             if (!gk.has(e)) gk.insert(e, make_key(context, 1, e, sw.get_stream()));
     }
     PhantomGaloisKey create_galois_keys_from_steps(const PhantomContext &context, const std::vector<int> &steps,
-                                                   const hip_stream_wrapper &sw) {
+                                                   const hip_stream_wrapper &sw = default_stream()) {
         std::vector<uint32_t> elts;
         for (int st : steps) {
             uint32_t e;
@@ -493,7 +531,7 @@ public:
     }
     // src/secretkey.cu:548-582
     void encrypt_symmetric(const PhantomContext &context, const PhantomPlaintext &plain, PhantomCiphertext &cipher,
-                           const hip_stream_wrapper &sw) {
+                           const hip_stream_wrapper &sw = default_stream()) {
         const hipStream_t &s = sw.get_stream();
         cipher.resize(context, plain.chain_index(), 2, s);
         const uint64_t seed_a = next_seed(), seed_e = next_seed();
@@ -504,7 +542,7 @@ public:
     }
     // src/secretkey.cu:584-643
     void decrypt(const PhantomContext &context, const PhantomCiphertext &cipher, PhantomPlaintext &plain,
-                 const hip_stream_wrapper &sw) {
+                 const hip_stream_wrapper &sw = default_stream()) {
         if (!cipher.is_ntt_form()) throw std::invalid_argument("encrypted must be in NTT form");
         const hipStream_t &s = sw.get_stream();
         plain.resize(cipher.coeff_modulus_size(), cipher.poly_modulus_degree(), s);
@@ -536,7 +574,7 @@ inline void keyswitch_inplace(const PhantomContext &c, PhantomCiphertext &encryp
 // ---- evaluator entry points (include/evaluate.cuh:114-294) ---------------------------------------
 // src/evaluate.cu:229-280,387-440
 inline void multiply_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2,
-                             const hip_stream_wrapper &stream_wrapper) {
+                             const hip_stream_wrapper &stream_wrapper = default_stream()) {
     if (!(encrypted1.is_ntt_form() && encrypted2.is_ntt_form()))
         throw std::invalid_argument("encrypted1 and encrypted2 must be in NTT form");
     if (encrypted1.chain_index() != encrypted2.chain_index())
@@ -556,7 +594,7 @@ inline void multiply_inplace(const PhantomContext &context, PhantomCiphertext &e
 
 // src/evaluate.cu:553-583
 inline void relinearize_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, const PhantomRelinKey &relin_keys,
-                                const hip_stream_wrapper &stream_wrapper) {
+                                const hip_stream_wrapper &stream_wrapper = default_stream()) {
     if (encrypted.size() != 3) throw std::invalid_argument("destination_size must be 3");
     if (!encrypted.is_ntt_form()) throw std::invalid_argument("CKKS encrypted must be in NTT form");
     const hipStream_t &s = stream_wrapper.get_stream();
@@ -567,14 +605,14 @@ inline void relinearize_inplace(const PhantomContext &context, PhantomCiphertext
 
 inline void multiply_and_relin_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1,
                                        const PhantomCiphertext &encrypted2, const PhantomRelinKey &relin_keys,
-                                       const hip_stream_wrapper &stream_wrapper) {
+                                       const hip_stream_wrapper &stream_wrapper = default_stream()) {
     multiply_inplace(context, encrypted1, encrypted2, stream_wrapper);
     relinearize_inplace(context, encrypted1, relin_keys, stream_wrapper);
 }
 
 // src/evaluate.cu:585-616,725-745
 inline PhantomCiphertext rescale_to_next(const PhantomContext &context, const PhantomCiphertext &encrypted,
-                                         const hip_stream_wrapper &stream_wrapper) {
+                                         const hip_stream_wrapper &stream_wrapper = default_stream()) {
     if (encrypted.chain_index() == context.size_Q()) throw std::invalid_argument("end of modulus switching chain reached");
     const hipStream_t &s = stream_wrapper.get_stream();
     PhantomCiphertext destination;
@@ -587,13 +625,13 @@ inline PhantomCiphertext rescale_to_next(const PhantomContext &context, const Ph
     return destination;
 }
 inline void rescale_to_next_inplace(const PhantomContext &context, PhantomCiphertext &encrypted,
-                                    const hip_stream_wrapper &stream_wrapper) {
+                                    const hip_stream_wrapper &stream_wrapper = default_stream()) {
     encrypted = rescale_to_next(context, encrypted, stream_wrapper);
 }
 
 // src/evaluate.cu:747-794
 inline void apply_galois_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, uint32_t galois_elt,
-                                 const PhantomGaloisKey &galois_keys, const hip_stream_wrapper &stream_wrapper) {
+                                 const PhantomGaloisKey &galois_keys, const hip_stream_wrapper &stream_wrapper = default_stream()) {
     if (encrypted.size() > 2) throw std::invalid_argument("encrypted size must be 2");
     const PhantomRelinKey &key = galois_keys.get_relin_keys(galois_elt);
     check(pha_apply_galois_inplace(context.handle(), encrypted.chain_index(), encrypted.data(), galois_elt,
@@ -602,17 +640,17 @@ inline void apply_galois_inplace(const PhantomContext &context, PhantomCiphertex
 
 // complex conjugation = the automorphism X -> X^(2N-1) (include/evaluate.cuh:283-294, src/evaluate.cu:855-870)
 inline void complex_conjugate_inplace(const PhantomContext &context, PhantomCiphertext &encrypted,
-                                      const PhantomGaloisKey &galois_key, const hip_stream_wrapper &stream_wrapper) {
+                                      const PhantomGaloisKey &galois_key, const hip_stream_wrapper &stream_wrapper = default_stream()) {
     apply_galois_inplace(context, encrypted, static_cast<uint32_t>(2 * context.poly_degree() - 1), galois_key, stream_wrapper);
 }
 
 // ---- element-wise evaluator entry points (include/evaluate.cuh:33-112,166-256, src/evaluate.cu:20-105,442-560,618-745)
-inline void negate_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, const hip_stream_wrapper &stream_wrapper) {
+inline void negate_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, const hip_stream_wrapper &stream_wrapper = default_stream()) {
     check(pha_negate_rns_poly(context.handle(), encrypted.data(), encrypted.data(), encrypted.coeff_modulus_size(),
                               encrypted.size(), stream_wrapper.get_stream()));
 }
 inline void add_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2,
-                        const hip_stream_wrapper &stream_wrapper) {
+                        const hip_stream_wrapper &stream_wrapper = default_stream()) {
     if (encrypted1.chain_index() != encrypted2.chain_index()) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
     if (encrypted1.is_ntt_form() != encrypted2.is_ntt_form()) throw std::invalid_argument("NTT form mismatch");
     if (encrypted1.size() != encrypted2.size()) throw std::invalid_argument("poly number mismatch");
@@ -620,7 +658,7 @@ inline void add_inplace(const PhantomContext &context, PhantomCiphertext &encryp
                            encrypted1.coeff_modulus_size(), encrypted1.size(), encrypted2.size(), stream_wrapper.get_stream()));
 }
 inline void sub_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2,
-                        const hip_stream_wrapper &stream_wrapper) {
+                        const hip_stream_wrapper &stream_wrapper = default_stream()) {
     if (encrypted1.chain_index() != encrypted2.chain_index()) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
     if (encrypted1.is_ntt_form() != encrypted2.is_ntt_form()) throw std::invalid_argument("NTT form mismatch");
     if (encrypted1.size() != encrypted2.size()) throw std::invalid_argument("poly number mismatch");
@@ -628,19 +666,19 @@ inline void sub_inplace(const PhantomContext &context, PhantomCiphertext &encryp
                            encrypted1.coeff_modulus_size(), encrypted1.size(), encrypted2.size(), stream_wrapper.get_stream()));
 }
 inline void add_plain_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, const PhantomPlaintext &plain,
-                              const hip_stream_wrapper &stream_wrapper) {
+                              const hip_stream_wrapper &stream_wrapper = default_stream()) {
     if (encrypted.chain_index() != plain.chain_index()) throw std::invalid_argument("encrypted and plain parameter mismatch");
     check(pha_add_rns_poly(context.handle(), encrypted.data(), encrypted.data(), plain.data(), encrypted.coeff_modulus_size(), 1,
                            1, stream_wrapper.get_stream()));
 }
 inline void sub_plain_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, const PhantomPlaintext &plain,
-                              const hip_stream_wrapper &stream_wrapper) {
+                              const hip_stream_wrapper &stream_wrapper = default_stream()) {
     if (encrypted.chain_index() != plain.chain_index()) throw std::invalid_argument("encrypted and plain parameter mismatch");
     check(pha_sub_rns_poly(context.handle(), encrypted.data(), encrypted.data(), plain.data(), encrypted.coeff_modulus_size(), 1,
                            1, stream_wrapper.get_stream()));
 }
 inline void multiply_plain_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, const PhantomPlaintext &plain,
-                                   const hip_stream_wrapper &stream_wrapper) {
+                                   const hip_stream_wrapper &stream_wrapper = default_stream()) {
     if (encrypted.chain_index() != plain.chain_index()) throw std::invalid_argument("encrypted and plain parameter mismatch");
     check(pha_multiply_rns_poly(context.handle(), encrypted.data(), encrypted.data(), plain.data(),
                                 encrypted.coeff_modulus_size(), encrypted.size(), 1, stream_wrapper.get_stream()));
@@ -648,7 +686,7 @@ inline void multiply_plain_inplace(const PhantomContext &context, PhantomCiphert
 }
 // CKKS mod_switch_to_next: drop the last prime, no scaling (src/evaluate.cu:618-723)
 inline PhantomCiphertext mod_switch_to_next(const PhantomContext &context, const PhantomCiphertext &encrypted,
-                                            const hip_stream_wrapper &stream_wrapper) {
+                                            const hip_stream_wrapper &stream_wrapper = default_stream()) {
     if (encrypted.chain_index() == context.size_Q()) throw std::invalid_argument("end of modulus switching chain reached");
     const hipStream_t &s = stream_wrapper.get_stream();
     PhantomCiphertext destination;
@@ -660,15 +698,114 @@ inline PhantomCiphertext mod_switch_to_next(const PhantomContext &context, const
     return destination;
 }
 inline void mod_switch_to_next_inplace(const PhantomContext &context, PhantomCiphertext &encrypted,
-                                       const hip_stream_wrapper &stream_wrapper) {
+                                       const hip_stream_wrapper &stream_wrapper = default_stream()) {
     encrypted = mod_switch_to_next(context, encrypted, stream_wrapper);
 }
 inline void mod_switch_to_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, size_t chain_index,
-                                  const hip_stream_wrapper &stream_wrapper) {
+                                  const hip_stream_wrapper &stream_wrapper = default_stream()) {
     if (encrypted.chain_index() > chain_index) throw std::invalid_argument("cannot switch to higher level modulus");
     while (encrypted.chain_index() != chain_index) mod_switch_to_next_inplace(context, encrypted, stream_wrapper);
 }
 
+
+// ---- out-of-place forms and the remaining entry points of include/evaluate.cuh:33-294 ------------------------
+// sub_inplace with the reference's `negate` flag: true computes encrypted1 = encrypted2 - encrypted1
+inline void sub_inplace(const PhantomContext &context, PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2,
+                        const bool &negate, const hip_stream_wrapper &stream_wrapper = default_stream()) {
+    sub_inplace(context, encrypted1, encrypted2, stream_wrapper);
+    if (negate) negate_inplace(context, encrypted1, stream_wrapper);
+}
+inline PhantomCiphertext negate(const PhantomContext &context, const PhantomCiphertext &encrypted,
+                                const hip_stream_wrapper &stream_wrapper = default_stream()) {
+    PhantomCiphertext destination = encrypted.clone(stream_wrapper.get_stream());
+    negate_inplace(context, destination, stream_wrapper);
+    return destination;
+}
+inline PhantomCiphertext add(const PhantomContext &context, const PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2,
+                             const hip_stream_wrapper &stream_wrapper = default_stream()) {
+    PhantomCiphertext destination = encrypted1.clone(stream_wrapper.get_stream());
+    add_inplace(context, destination, encrypted2, stream_wrapper);
+    return destination;
+}
+// destination = encrypteds[0] + encrypteds[1] + ...
+inline void add_many(const PhantomContext &context, const std::vector<PhantomCiphertext> &encrypteds, PhantomCiphertext &destination,
+                     const hip_stream_wrapper &stream_wrapper = default_stream()) {
+    if (encrypteds.empty()) throw std::invalid_argument("encrypteds cannot be empty");
+    PhantomCiphertext sum = encrypteds[0].clone(stream_wrapper.get_stream());
+    for (size_t i = 1; i < encrypteds.size(); i++) add_inplace(context, sum, encrypteds[i], stream_wrapper);
+    destination = std::move(sum);
+}
+inline PhantomCiphertext sub(const PhantomContext &context, const PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2,
+                             const bool &negate = false, const hip_stream_wrapper &stream_wrapper = default_stream()) {
+    PhantomCiphertext destination = encrypted1.clone(stream_wrapper.get_stream());
+    sub_inplace(context, destination, encrypted2, negate, stream_wrapper);
+    return destination;
+}
+inline PhantomCiphertext multiply(const PhantomContext &context, const PhantomCiphertext &encrypted1, const PhantomCiphertext &encrypted2,
+                                  const hip_stream_wrapper &stream_wrapper = default_stream()) {
+    PhantomCiphertext destination = encrypted1.clone(stream_wrapper.get_stream());
+    multiply_inplace(context, destination, &encrypted1 == &encrypted2 ? destination : encrypted2, stream_wrapper);
+    return destination;
+}
+inline PhantomCiphertext relinearize(const PhantomContext &context, const PhantomCiphertext &encrypted, const PhantomRelinKey &relin_keys,
+                                     const hip_stream_wrapper &stream_wrapper = default_stream()) {
+    PhantomCiphertext destination = encrypted.clone(stream_wrapper.get_stream());
+    relinearize_inplace(context, destination, relin_keys, stream_wrapper);
+    return destination;
+}
+inline PhantomCiphertext multiply_and_relin(const PhantomContext &context, const PhantomCiphertext &encrypted1,
+                                            const PhantomCiphertext &encrypted2, const PhantomRelinKey &relin_keys,
+                                            const hip_stream_wrapper &stream_wrapper = default_stream()) {
+    PhantomCiphertext destination = encrypted1.clone(stream_wrapper.get_stream());
+    multiply_and_relin_inplace(context, destination, &encrypted1 == &encrypted2 ? destination : encrypted2, relin_keys, stream_wrapper);
+    return destination;
+}
+inline PhantomCiphertext add_plain(const PhantomContext &context, const PhantomCiphertext &encrypted, const PhantomPlaintext &plain,
+                                   const hip_stream_wrapper &stream_wrapper = default_stream()) {
+    PhantomCiphertext destination = encrypted.clone(stream_wrapper.get_stream());
+    add_plain_inplace(context, destination, plain, stream_wrapper);
+    return destination;
+}
+inline PhantomCiphertext sub_plain(const PhantomContext &context, const PhantomCiphertext &encrypted, const PhantomPlaintext &plain,
+                                   const hip_stream_wrapper &stream_wrapper = default_stream()) {
+    PhantomCiphertext destination = encrypted.clone(stream_wrapper.get_stream());
+    sub_plain_inplace(context, destination, plain, stream_wrapper);
+    return destination;
+}
+inline PhantomCiphertext multiply_plain(const PhantomContext &context, const PhantomCiphertext &encrypted, const PhantomPlaintext &plain,
+                                        const hip_stream_wrapper &stream_wrapper = default_stream()) {
+    PhantomCiphertext destination = encrypted.clone(stream_wrapper.get_stream());
+    multiply_plain_inplace(context, destination, plain, stream_wrapper);
+    return destination;
+}
+inline PhantomCiphertext mod_switch_to(const PhantomContext &context, const PhantomCiphertext &encrypted, size_t chain_index,
+                                       const hip_stream_wrapper &stream_wrapper = default_stream()) {
+    if (encrypted.chain_index() > chain_index) throw std::invalid_argument("cannot switch to higher level modulus");
+    PhantomCiphertext destination = encrypted.clone(stream_wrapper.get_stream());
+    mod_switch_to_inplace(context, destination, chain_index, stream_wrapper);
+    return destination;
+}
+// plaintexts (include/evaluate.cuh:211-256)
+inline void mod_switch_to_next_inplace(const PhantomContext &, PhantomPlaintext &plain, const hip_stream_wrapper & = default_stream()) {
+    plain.drop_last_limb();
+}
+inline void mod_switch_to_inplace(const PhantomContext &context, PhantomPlaintext &plain, size_t chain_index,
+                                  const hip_stream_wrapper &stream_wrapper = default_stream()) {
+    if (plain.chain_index() > chain_index) throw std::invalid_argument("cannot switch to higher level modulus");
+    while (plain.chain_index() != chain_index) mod_switch_to_next_inplace(context, plain, stream_wrapper);
+}
+inline PhantomCiphertext apply_galois(const PhantomContext &context, const PhantomCiphertext &encrypted, uint32_t galois_elt,
+                                      const PhantomGaloisKey &galois_keys, const hip_stream_wrapper &stream_wrapper = default_stream()) {
+    PhantomCiphertext destination = encrypted.clone(stream_wrapper.get_stream());
+    apply_galois_inplace(context, destination, galois_elt, galois_keys, stream_wrapper);
+    return destination;
+}
+inline PhantomCiphertext complex_conjugate(const PhantomContext &context, const PhantomCiphertext &encrypted,
+                                           const PhantomGaloisKey &galois_key, const hip_stream_wrapper &stream_wrapper = default_stream()) {
+    PhantomCiphertext destination = encrypted.clone(stream_wrapper.get_stream());
+    complex_conjugate_inplace(context, destination, galois_key, stream_wrapper);
+    return destination;
+}
 
 // non-adjacent form of a rotation step (the reference falls back to it when no key exists for
 // the step itself, src/evaluate.cu:821-839)
@@ -690,7 +827,7 @@ inline std::vector<int> naf(int value) {
 
 // src/evaluate.cu:797-852
 inline void rotate_inplace(const PhantomContext &context, PhantomCiphertext &encrypted, int step,
-                           const PhantomGaloisKey &galois_key, const hip_stream_wrapper &stream_wrapper) {
+                           const PhantomGaloisKey &galois_key, const hip_stream_wrapper &stream_wrapper = default_stream()) {
     if (step == 0) return;
     uint32_t elt = 0;
     check(pha_galois_elt_from_step(context.log_n(), step, &elt));
@@ -704,6 +841,13 @@ inline void rotate_inplace(const PhantomContext &context, PhantomCiphertext &enc
         if (static_cast<size_t>(std::abs(part)) != (context.poly_degree() >> 1))
             rotate_inplace(context, encrypted, part, galois_key, stream_wrapper);
     }
+}
+
+inline PhantomCiphertext rotate(const PhantomContext &context, const PhantomCiphertext &encrypted, int step,
+                                const PhantomGaloisKey &galois_key, const hip_stream_wrapper &stream_wrapper = default_stream()) {
+    PhantomCiphertext destination = encrypted.clone(stream_wrapper.get_stream());
+    rotate_inplace(context, destination, step, galois_key, stream_wrapper);
+    return destination;
 }
 
 }  // namespace phantom

@@ -128,6 +128,50 @@ int main() {
                    a.coeff_modulus_size());
         }
 
+        // out-of-place forms with the default stream argument, like the reference's tests call them (tests/add.cu,
+        // add_many.cu, negation.cu, mod_switch_to_inplace.cu): each must equal its in-place twin
+        {
+            check_hip(hipDeviceSynchronize(), "sync");
+            PhantomCiphertext a = make_ct(context, moduli, 1, 57, 58, s), b = make_ct(context, moduli, 1, 67, 68, s);
+            check_hip(hipDeviceSynchronize(), "sync");
+            PhantomCiphertext sum = add(context, a, b);                 // default stream
+            PhantomCiphertext a2 = a;                                   // deep copy
+            add_inplace(context, a2, b);
+            check_hip(hipDeviceSynchronize(), "sync");
+            int ok = fnv(download(sum)) == fnv(download(a2));
+            PhantomCiphertext d1 = sub(context, a, b, true);            // b - a
+            PhantomCiphertext d2 = sub(context, b, a);
+            check_hip(hipDeviceSynchronize(), "sync");
+            ok += fnv(download(d1)) == fnv(download(d2));
+            std::vector<PhantomCiphertext> many;
+            many.push_back(a);
+            many.push_back(b);
+            many.push_back(a);
+            PhantomCiphertext total, twice = add(context, sum, a);
+            add_many(context, many, total);
+            check_hip(hipDeviceSynchronize(), "sync");
+            ok += fnv(download(total)) == fnv(download(twice));
+            PhantomCiphertext n1 = negate(context, a), lower = mod_switch_to(context, a, 3);
+            PhantomCiphertext a3 = a;
+            negate_inplace(context, a3);
+            check_hip(hipDeviceSynchronize(), "sync");
+            ok += fnv(download(n1)) == fnv(download(a3)) && lower.coeff_modulus_size() == 2 && a.coeff_modulus_size() == 4;
+            PhantomCiphertext r1 = rotate(context, a, 1, gk), r2 = a;
+            rotate_inplace(context, r2, 1, gk);
+            PhantomCiphertext m1 = multiply_and_relin(context, a, b, rlk), m2 = a;
+            multiply_and_relin_inplace(context, m2, b, rlk);
+            check_hip(hipDeviceSynchronize(), "sync");
+            ok += fnv(download(r1)) == fnv(download(r2));
+            ok += fnv(download(m1)) == fnv(download(m2)) && m1.size() == 2;
+            PhantomPlaintext pl;
+            pl.resize(4, n, s);
+            pl.set_chain_index(1);
+            PhantomPlaintext pl2 = pl;
+            mod_switch_to_inplace(context, pl2, 3);
+            ok += pl2.coeff_modulus_size() == 2 && pl2.chain_index() == 3 && pl.coeff_modulus_size() == 4;
+            printf("{\"out_of_place_ok\": %d}\n", ok);
+        }
+
         // real keys: keygen -> encrypt -> HMult+relin -> decrypt (tests/relin.cu), all on the GPU.
         // Plaintexts are the constant polynomials 3*2^20 and 5*2^20 (in NTT form a constant is the
         // same residue in every slot), so the product must decrypt to 15*2^40 + small noise in

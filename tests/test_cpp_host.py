@@ -108,6 +108,7 @@ def test_cpp_host_layer_against_oracle(gpu, orc):
     assert res["neg_sub"] == digest(ns)
     assert res["mod_switch_to_3"] == digest(ns[:, :2]) and res["ms_limbs"] == 2
     assert res["errors_caught"] == 5
+    assert res["out_of_place_ok"] == 7       # add / sub(negate) / add_many / negate + mod_switch_to / rotate / multiply_and_relin / plaintext
     # keygen -> encrypt -> HMult+relin -> decrypt with real keys: product of the constants, small noise
     assert res["real_keys_rel_err"] < 1e-3 and res["real_keys_rest"] < 1e-3
     assert res["gen_twice_throws"] == 1
