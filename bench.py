@@ -185,6 +185,34 @@ def secondary_metrics(torch, pha):
     res["bootstrap_ms"] = 1e3 * min(times)
     res["bootstrap_config"] = f"N=2^16, {slots} sparse slots, {len(q_bits)} Q limbs + {alpha} special primes, h=192, scale 2^{d}"
     ctx.close()
+    del ev, bs, ct, out
+
+    # full slots (BASELINE configs[4]'s primitive): 32768 slots, messages at 2^46, EvalMod at 2^58, four levels per
+    # linear transform, 13 levels left after the bootstrap
+    d, e, slots, groups = 46, 58, N // 2, 4
+    q_bits = [d + 10] + [d] * 13 + [d] * groups + [e] * 10 + [60] * groups
+    while len(q_bits) % alpha:
+        q_bits.insert(1, d)
+    mods = pha.coeff_modulus_create(N, q_bits + [60] * alpha)
+    ctx = pha.PhantomContext(LOG_N, mods, alpha)
+    ev = GpuEvaluator(pha, ctx, ctx.gen_secretkey(21, hamming_weight=192), slots)
+    bs = Bootstrapper(ev, K=25, r=4, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d, transform="fft", c2s_groups=groups,
+                      s2c_groups=groups)
+    msg = np.random.default_rng(4).uniform(-1, 1, slots) + 1j * np.random.default_rng(5).uniform(-1, 1, slots)
+    ct = ev.encrypt(ev.encode(msg, 2.0 ** d, ev.bottom))
+    out = bs.bootstrap(ct)
+    res["bootstrap_full_slots_max_abs_error"] = float(np.abs(ev.decrypt_decode(out) - msg).max())
+    times = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bs.bootstrap(ct)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    res["bootstrap_full_slots_ms"] = 1e3 * min(times)
+    res["bootstrap_full_slots_config"] = (f"N=2^16, {slots} slots, {len(q_bits)} Q limbs + {alpha} special primes, h=192, message scale "
+                                          f"2^{d}, EvalMod at 2^{e}, {ev.limbs(out.level) - 1} levels left")
+    ctx.close()
     return res
 
 
