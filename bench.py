@@ -188,9 +188,9 @@ def secondary_metrics(torch, pha):
     del ev, bs, ct, out
 
     # full slots (BASELINE configs[4]'s primitive): 32768 slots, messages at 2^46, EvalMod at 2^58, four levels per
-    # linear transform, 13 levels left after the bootstrap
+    # linear transform, 9 levels left after the bootstrap; log2(QP) = 1714, inside the 1761-bit bound for N = 2^16
     d, e, slots, groups = 46, 58, N // 2, 4
-    q_bits = [d + 10] + [d] * 13 + [d] * groups + [e] * 10 + [60] * groups
+    q_bits = [d + 10] + [d] * 9 + [d] * groups + [e] * 10 + [60] * groups
     while len(q_bits) % alpha:
         q_bits.insert(1, d)
     mods = pha.coeff_modulus_create(N, q_bits + [60] * alpha)
@@ -211,7 +211,8 @@ def secondary_metrics(torch, pha):
         times.append(time.perf_counter() - t0)
     res["bootstrap_full_slots_ms"] = 1e3 * min(times)
     res["bootstrap_full_slots_config"] = (f"N=2^16, {slots} slots, {len(q_bits)} Q limbs + {alpha} special primes, h=192, message scale "
-                                          f"2^{d}, EvalMod at 2^{e}, {ev.limbs(out.level) - 1} levels left")
+                                          f"2^{d}, EvalMod at 2^{e}, {ev.limbs(out.level) - 1} levels left, log2(QP) = "
+                                          f"{float(sum(np.log2(np.array(mods, dtype=np.float64)))):.0f}")
     ctx.close()
     return res
 

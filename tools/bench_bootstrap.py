@@ -60,7 +60,7 @@ def main():
         times.append(time.perf_counter() - t0)
     print(json.dumps({"metric": "CKKS bootstrap ms", "transform": args.transform, "value": 1e3 * min(times), "unit": "ms", "log_n": args.log_n,
                       "slots": args.slots, "delta_bits": d, "evalmod_bits": e, "q_limbs": len(q_bits), "special_primes": args.alpha, "levels_after": ev.limbs(out.level) - 1,
-                      "max_abs_error": err, "setup_s": setup_s, "rotation_keys": len(ev.galois), "n_gpus": 1}), flush=True)
+                      "max_abs_error": err, "log_qp": round(float(sum(np.log2(np.array(mods, dtype=np.float64)))), 1), "setup_s": setup_s, "rotation_keys": len(ev.galois), "n_gpus": 1}), flush=True)
     ctx.close()
 
 
