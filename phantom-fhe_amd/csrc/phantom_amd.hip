@@ -131,6 +131,9 @@ struct pha_context {
     std::map<uint32_t, std::unique_ptr<DevBuf<uint32_t>>> galois_tables;
     DevBuf<uint64_t> workspace;
     DevBuf<uint64_t> d_bigP_mod_q;  // key level, [size_Q] (key generation)
+    // helper stream for the independent giant-step chains of pha_linear_transform_double_hoisted
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     // CKKS encoder: rotation group 5^j mod 2N and per-level CRT composition tables
     struct EncoderLevel {
         DevBuf<uint64_t> big_q, half_q, qhat, inv_qhat;
@@ -1034,6 +1037,9 @@ int pha_context_create(int log_n, const uint64_t *moduli_QP, size_t size_QP, siz
 void pha_context_destroy(pha_context *ctx) {
     if (!ctx) return;
     (void)hipDeviceSynchronize();
+    if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
+    if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     delete ctx;
 }
 
@@ -1720,37 +1726,71 @@ int pha_linear_transform_double_hoisted(pha_context *ctx, size_t chain_index, co
         build_level_constants(ctx->moduli, ctx->size_P, ctx->size_Q, lc);
         HIP_TRY(ctx->d_bigP_mod_q.upload(lc.bigP_mod_q));
     }
+    // Giant steps that rotate are independent chains (moddown -> modup -> inner product) of small, latency-bound
+    // launches: with two or more of them, every other chain runs on the context's helper stream with its own buffers.
+    size_t rotating = 0;
+    for (size_t g = 0; g < n_giant; g++) rotating += giant_elts_host[g] != 1;
+    static const bool two_streams_ok = [] {
+        const char *e = getenv("PHA_GIANT_STREAMS");
+        return !(e && e[0] == '1');
+    }();
+    const bool two = two_streams_ok && rotating >= 2;
+    if (two && !ctx->aux_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming));
+    }
+    const size_t chain_words = ((lt->beta + 6) * size_QlP + 4 * size_Ql) * n;   // t_mod_up | cx | acc | total | scratch | u
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + (2 * n_baby + 6) * size_QlP + 4 * size_Ql) * n, &ws));
-    uint64_t *t_mod_up = ws, *cx = t_mod_up + lt->beta * size_QlP * n, *acc = cx + 2 * size_QlP * n,
-             *total = acc + 2 * size_QlP * n, *rot = total + 2 * size_QlP * n, *scratch = rot + 2 * n_baby * size_QlP * n,
-             *u = scratch + 2 * size_Ql * n;
+    PHA_TRY(ensure_workspace(ctx, (two ? 2 : 1) * chain_words + 2 * n_baby * size_QlP * n, &ws));
+    struct Chain {
+        hipStream_t st;
+        uint64_t *t_mod_up, *cx, *acc, *total, *scratch, *u;
+        bool first;
+    } chains[2];
+    for (int c = 0; c < 2; c++) {
+        uint64_t *base = ws + c * chain_words;
+        chains[c] = Chain{c ? ctx->aux_stream : st, base, base + lt->beta * size_QlP * n, base + (lt->beta + 2) * size_QlP * n,
+                          base + (lt->beta + 4) * size_QlP * n, base + (lt->beta + 6) * size_QlP * n,
+                          base + (lt->beta + 6) * size_QlP * n + 2 * size_Ql * n, true};
+    }
+    uint64_t *rot = ws + (two ? 2 : 1) * chain_words;
     const uint32_t n32 = static_cast<uint32_t>(n), ql = static_cast<uint32_t>(size_Ql), qlp = static_cast<uint32_t>(size_QlP),
                    sq = static_cast<uint32_t>(ctx->size_Q);
     const dim3 grid_qp(qlp * (n32 / 512), 2), grid_qp1(qlp * (n32 / 512), 1);
     const DModulus *mod = ctx->d_mod.p;
-    auto perm_of = [&](uint32_t elt, const uint32_t **perm) -> int {
-        *perm = nullptr;
-        return elt == 1 ? PHA_OK : get_galois_table(ctx, elt, perm);
-    };
-    // dst_qp = key switch of src's c1 under elt (t_mod_up must hold modup(src c1)) + lifted pi(c0)
-    auto rotate_qp = [&](uint64_t *dst_qp, const uint64_t *src, uint32_t elt, const uint64_t *const *evks) -> int {
-        const uint32_t *perm;
-        PHA_TRY(perm_of(elt, &perm));
+    // dst_qp = key switch of src's c1 under elt (ch.t_mod_up must hold modup(src c1)) + lifted pi(c0), on ch's stream
+    auto rotate_qp = [&](Chain &ch, uint64_t *dst_qp, const uint64_t *src, uint32_t elt, const uint64_t *const *evks) -> int {
+        const uint32_t *perm = nullptr;
         if (elt == 1) {
-            hipLaunchKernelGGL((lift_qp_kernel<true>), grid_qp, dim3(256), 0, st, dst_qp, src, perm, ctx->d_bigP_mod_q.p, mod, n32, ql, qlp);
+            hipLaunchKernelGGL((lift_qp_kernel<true>), grid_qp, dim3(256), 0, ch.st, dst_qp, src, perm, ctx->d_bigP_mod_q.p, mod, n32, ql, qlp);
             return check_launch("lift_qp");
         }
+        PHA_TRY(get_galois_table(ctx, elt, &perm));
         if (!evks) return fail(PHA_ERR_INVALID_ARGUMENT, "null Galois key");
-        PHA_TRY(do_inner_prod(ctx, lt, dst_qp, t_mod_up, evks, st, perm));
-        hipLaunchKernelGGL((lift_qp_kernel<false>), grid_qp1, dim3(256), 0, st, dst_qp, src, perm, ctx->d_bigP_mod_q.p, mod, n32, ql, qlp);
+        PHA_TRY(do_inner_prod(ctx, lt, dst_qp, ch.t_mod_up, evks, ch.st, perm));
+        hipLaunchKernelGGL((lift_qp_kernel<false>), grid_qp1, dim3(256), 0, ch.st, dst_qp, src, perm, ctx->d_bigP_mod_q.p, mod, n32, ql, qlp);
         return check_launch("lift_qp");
     };
+    auto accumulate = [&](Chain &ch, const uint64_t *add) -> int {
+        if (ch.first)
+            hipLaunchKernelGGL((add_qp_kernel<true>), grid_qp, dim3(256), 0, ch.st, ch.total, add, mod, n32, ql, qlp, sq);
+        else
+            hipLaunchKernelGGL((add_qp_kernel<false>), grid_qp, dim3(256), 0, ch.st, ch.total, add, mod, n32, ql, qlp, sq);
+        ch.first = false;
+        return check_launch("add_qp");
+    };
+    Chain &main_chain = chains[0];
     bool any_rot = false;
     for (size_t b = 0; b < n_baby; b++) any_rot = any_rot || baby_elts_host[b] != 1;
-    if (any_rot) PHA_TRY(do_modup(ctx, lt, t_mod_up, ct + size_Ql * n, scratch, st));
-    for (size_t b = 0; b < n_baby; b++) PHA_TRY(rotate_qp(rot + 2 * b * size_QlP * n, ct, baby_elts_host[b], baby_evks_host[b]));
-    bool first = true;
+    if (any_rot) PHA_TRY(do_modup(ctx, lt, main_chain.t_mod_up, ct + size_Ql * n, main_chain.scratch, st));
+    for (size_t b = 0; b < n_baby; b++)
+        PHA_TRY(rotate_qp(main_chain, rot + 2 * b * size_QlP * n, ct, baby_elts_host[b], baby_evks_host[b]));
+    if (two) {  // the helper stream starts once the baby rotations exist
+        HIP_TRY(hipEventRecord(ctx->aux_fork, st));
+        HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
+    }
+    size_t rot_index = 0;
     for (size_t g = 0; g < n_giant; g++) {
         MacTerms terms{};
         for (size_t b = 0; b < n_baby; b++) {
@@ -1760,24 +1800,26 @@ int pha_linear_transform_double_hoisted(pha_context *ctx, size_t chain_index, co
             terms.pt[terms.count++] = pt;
         }
         if (!terms.count) continue;
-        hipLaunchKernelGGL(multi_mac_qp_kernel, dim3(qlp * (n32 / 512)), dim3(256), 0, st, acc, terms, mod, n32, ql, qlp, sq);
+        const bool rotates = giant_elts_host[g] != 1;
+        Chain &ch = chains[(two && rotates) ? (rot_index++ & 1) : 0];
+        hipLaunchKernelGGL(multi_mac_qp_kernel, dim3(qlp * (n32 / 512)), dim3(256), 0, ch.st, ch.acc, terms, mod, n32, ql, qlp, sq);
         PHA_TRY(check_launch("multi_mac_qp"));
-        const uint64_t *add = acc;
-        if (giant_elts_host[g] != 1) {
-            PHA_TRY(do_moddown(ctx, lt, u, acc, scratch, nullptr, 2, st));
-            PHA_TRY(do_modup(ctx, lt, t_mod_up, u + size_Ql * n, scratch, st));
-            PHA_TRY(rotate_qp(cx, u, giant_elts_host[g], giant_evks_host[g]));
-            add = cx;
+        const uint64_t *add = ch.acc;
+        if (rotates) {
+            PHA_TRY(do_moddown(ctx, lt, ch.u, ch.acc, ch.scratch, nullptr, 2, ch.st));
+            PHA_TRY(do_modup(ctx, lt, ch.t_mod_up, ch.u + size_Ql * n, ch.scratch, ch.st));
+            PHA_TRY(rotate_qp(ch, ch.cx, ch.u, giant_elts_host[g], giant_evks_host[g]));
+            add = ch.cx;
         }
-        if (first)
-            hipLaunchKernelGGL((add_qp_kernel<true>), grid_qp, dim3(256), 0, st, total, add, mod, n32, ql, qlp, sq);
-        else
-            hipLaunchKernelGGL((add_qp_kernel<false>), grid_qp, dim3(256), 0, st, total, add, mod, n32, ql, qlp, sq);
-        PHA_TRY(check_launch("add_qp"));
-        first = false;
+        PHA_TRY(accumulate(ch, add));
     }
-    if (first) return fail(PHA_ERR_INVALID_ARGUMENT, "the transform has no plaintext");
-    return do_moddown(ctx, lt, out, total, scratch, nullptr, 2, st);
+    if (two) {  // join: the helper chain's partial sum goes into the main one
+        HIP_TRY(hipEventRecord(ctx->aux_join, ctx->aux_stream));
+        HIP_TRY(hipStreamWaitEvent(st, ctx->aux_join, 0));
+        if (!chains[1].first) PHA_TRY(accumulate(main_chain, chains[1].total));
+    }
+    if (main_chain.first) return fail(PHA_ERR_INVALID_ARGUMENT, "the transform has no plaintext");
+    return do_moddown(ctx, lt, out, main_chain.total, main_chain.scratch, nullptr, 2, st);
 }
 
 // apply_galois_inplace on `batch` independent ciphertexts that share the Galois element and its key

@@ -265,9 +265,10 @@ def test_double_hoisted_linear_transform(gpu, pha, orc, size_p, chain_index):
     tqp = tq + [o.size_Q + i for i in range(size_p)]
     ct = np.stack([o.uniform_poly(tq, 401), o.uniform_poly(tq, 402)])
     baby_elts = [1] + [orc.galois_elt_from_step(12, s) for s in (1, 2)]
-    giant_elts = [1, orc.galois_elt_from_step(12, 4)]
+    # three rotating giant steps: two run on the library's helper stream chain, results must not depend on it
+    giant_elts = [1] + [orc.galois_elt_from_step(12, s) for s in (4, 8, 12)]
     keys = {e: _uniform_evk(pha, o, 500 + 7 * i) for i, e in enumerate(baby_elts[1:] + giant_elts[1:])}
-    plains = [[o.uniform_poly(tqp, 600 + 10 * g + b) if (g, b) != (1, 1) else None for b in range(3)] for g in range(2)]
+    plains = [[o.uniform_poly(tqp, 600 + 10 * g + b) if (g, b) != (1, 1) else None for b in range(3)] for g in range(4)]
     ref = linear_transform_double_hoisted_ref(o, size_ql, ct, baby_elts, [keys[e][0] if e != 1 else None for e in baby_elts],
                                               giant_elts, [keys[e][0] if e != 1 else None for e in giant_elts], plains)
     d_pl = [[_dev(pha, p) if p is not None else None for p in row] for row in plains]
@@ -277,8 +278,8 @@ def test_double_hoisted_linear_transform(gpu, pha, orc, size_p, chain_index):
     assert (_host(pha, out) == ref).all()
     # a transform whose only giant step rotates, and one without any rotation
     out = ctx.linear_transform_double_hoisted(chain_index, _dev(pha, ct), baby_elts[:2], [None, keys[baby_elts[1]][1]],
-                                              giant_elts[1:], [keys[giant_elts[1]][1]], [d_pl[1][:2]])
-    ref = linear_transform_double_hoisted_ref(o, size_ql, ct, baby_elts[:2], [None, keys[baby_elts[1]][0]], giant_elts[1:],
+                                              giant_elts[1:2], [keys[giant_elts[1]][1]], [d_pl[1][:2]])
+    ref = linear_transform_double_hoisted_ref(o, size_ql, ct, baby_elts[:2], [None, keys[baby_elts[1]][0]], giant_elts[1:2],
                                               [keys[giant_elts[1]][0]], [plains[1][:2]])
     assert (_host(pha, out) == ref).all()
     out = ctx.linear_transform_double_hoisted(chain_index, _dev(pha, ct), [1], [None], [1], [None], [[d_pl[0][0]]])
