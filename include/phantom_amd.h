@@ -293,6 +293,15 @@ int pha_rotate_hoisted(pha_context *ctx, size_t chain_index, const uint64_t *ct,
                        const uint32_t *galois_elts_host, const uint64_t *const *const *evks_host,
                        uint64_t *const *out_host, pha_stream_t stream);
 
+/* multiply + relinearize + rescale_to_next (src/evaluate.cu:229-280,553-616) as ONE composite: out[2][l-1][N] from
+ * ct1, ct2 [2][l][N] (ct1 == ct2 squares); times2 != 0 also doubles the result (a Chebyshev product 2 T_a T_b).
+ * The tensor's first two polys are lifted over Q_l u P and the key-switched third, and one moddown divides by
+ * P * q_{l-1}: one NTT pass over the ciphertext less than the three calls, no last-limb INTT / broadcast.  The result
+ * equals rescale(relinearize(multiply)) up to the rounding of the divisions (a few units); the reference has no
+ * counterpart.  ct1 and ct2 are preserved. */
+int pha_multiply_relin_rescale(pha_context *ctx, size_t chain_index, const uint64_t *ct1, const uint64_t *ct2,
+                               const uint64_t *const *relin_evks, uint64_t *out, int times2, pha_stream_t stream);
+
 /* apply_galois_inplace (src/evaluate.cu:747-794) on `batch` independent ciphertexts sharing the Galois element and
  * its key: in / out are [batch][2][l][N] contiguous, out of place (BASELINE configs[3], rotate x 64).  Results are
  * bit-identical to `batch` calls of pha_apply_galois_inplace; the reference has no batched entry point. */

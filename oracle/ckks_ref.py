@@ -294,3 +294,54 @@ def linear_transform_double_hoisted_ref(o, size_ql, ct, baby_elts, baby_keys, gi
         add = acc if ge == 1 else rotate_qp(moddown2(acc), ge, gk)
         total = add if total is None else addmod(total, add)
     return moddown2(total)
+
+
+# ---- merged relinearise + rescale, restated from the oracle's primitives ------------------------------
+def multiply_relin_rescale_ref(o, size_ql, ct1, ct2, rlk, times2=False):
+    """out[2][size_ql-1][n] as include/phantom_amd.h describes pha_multiply_relin_rescale: tensor product, key switch
+    of the third poly kept over Q_l u P, the first two polys lifted by P, and ONE division by B = {q_{l-1}} u P with
+    an exact, centred base conversion (y_b = x_b * BHat_b^-1 mod b; e = rint(sum_b y_b / b);
+    delta_j = sum_b y_b * (BHat_b mod q_j) - e * prod B; out_j = (x_j - delta_j) * (prod B)^-1 mod q_j), INTT / NTT as
+    in moddown_from_NTT: the quotient is rounded to nearest."""
+    n, size_p, size_q = o.n, o.size_P, o.size_Q
+    qlp = size_ql + size_p
+    tidx = list(range(size_ql)) + [size_q + i for i in range(size_p)]
+    mods = [int(o.moduli[t]) for t in tidx]
+    big_p = o.level_constants(size_ql)["bigP_mod_q"]
+    d = o.tensor_prod_2x2(np.ascontiguousarray(ct1), np.ascontiguousarray(ct2))
+    if times2:      # the doubling is taken on the tensor product, before any division
+        for j in range(size_ql):
+            d[:, j] = np.array((d[:, j].astype(object) * 2) % mods[j], dtype=np.uint64)
+    t = o.modup(size_ql, np.ascontiguousarray(d[2]))
+    cx = o.key_switch_inner_prod(size_ql, t, rlk)
+    for i in range(2):
+        for j in range(size_ql):
+            lifted = _mulmod_vec(d[i][j], np.full(n, int(big_p[j]), dtype=np.uint64), mods[j])
+            cx[i, j] = np.array((cx[i, j].astype(object) + lifted.astype(object)) % mods[j], dtype=np.uint64)
+    base = list(range(size_ql - 1, qlp))                     # buffer limbs of B: q_{l-1}, then P
+    bmods = [mods[b] for b in base]
+    prod_b = 1
+    for m in bmods:
+        prod_b *= m
+    out = np.zeros((2, size_ql - 1, n), dtype=np.uint64)
+    for i in range(2):
+        ys = []
+        v = np.zeros(n, dtype=np.float64)
+        for b, m in zip(base, bmods):
+            coeff = o.ntt_inv(np.ascontiguousarray(cx[i, b]), tidx[b])
+            hat_inv = pow((prod_b // m) % m, -1, m)
+            y = _mulmod_vec(coeff, np.full(n, hat_inv, dtype=np.uint64), m)
+            # e = rint(sum_b y_b / b) in FP64, products and sums in this order (bconv_centred_kernel)
+            v = v + y.astype(np.float64) * np.float64(1.0 / float(m))
+            ys.append(y.astype(object))
+        e = np.rint(v).astype(np.uint64).astype(object)
+        for j in range(size_ql - 1):
+            q = mods[j]
+            delta = e * ((q - prod_b % q) % q)
+            for y, m in zip(ys, bmods):
+                delta = delta + y * ((prod_b // m) % q)
+            delta_ntt = o.ntt_fwd(np.array(delta % q, dtype=np.uint64), j)
+            inv = pow(prod_b % q, -1, q)
+            diff = (cx[i, j].astype(object) + q - delta_ntt.astype(object)) % q
+            out[i, j] = np.array(diff * inv % q, dtype=np.uint64)
+    return out

@@ -93,6 +93,7 @@ SIGNATURES = {
     "pha_ckks_encode": (_int, [_vp, _vp, _sz, _sz, _sz, ctypes.c_double, _vp, _vp]),
     "pha_ckks_decode": (_int, [_vp, _vp, _sz, ctypes.c_double, _sz, _vp, _vp]),
     "pha_rotate_hoisted": (_int, [_vp, _sz, _vp, _sz, _u32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
+    "pha_multiply_relin_rescale": (_int, [_vp, _sz, _vp, _vp, _vp, _vp, _int, _vp]),
     "pha_apply_galois_batched": (_int, [_vp, _sz, _vp, _vp, _sz, _u32, _vp, _vp]),
     "pha_ckks_encode_qp": (_int, [_vp, _vp, _sz, _sz, _sz, ctypes.c_double, _vp, _vp]),
     "pha_linear_transform_double_hoisted": (_int, [_vp, _sz, _vp, _sz, _u32p, ctypes.POINTER(_vp), _sz, _u32p, ctypes.POINTER(_vp),
@@ -484,6 +485,13 @@ class PhantomContext:
         out_ptrs = (_vp * len(outs))(*[o.data_ptr() for o in outs])
         _check(lib().pha_rotate_hoisted(self._h, chain_index, _ptr(ct), len(outs), elts, keys, out_ptrs, _stream()))
         return outs
+
+    def multiply_relin_rescale(self, chain_index, ct1, ct2, relin_key, times2=False):
+        """rescale(relinearize(ct1 * ct2)) (x 2) as one composite with a single moddown; out [2][l-1][N]"""
+        out = self._empty(2, ct1.shape[1] - 1)
+        _check(lib().pha_multiply_relin_rescale(self._h, chain_index, _ptr(ct1), _ptr(ct2), relin_key.ptr, _ptr(out),
+                                                1 if times2 else 0, _stream()))
+        return out
 
     def apply_galois_batched(self, chain_index, cts, galois_elt, galois_key):
         """cts [batch][2][l][N] -> rotated copies, one launch sequence for the whole batch"""

@@ -198,7 +198,7 @@ class ChebyshevEvaluator:
         ev = self.ev
         x, y = T[a], T[b]
         lvl = max(x.level, y.level)
-        p = ev.rescale(ev.double(ev.mul(ev.drop(x, lvl), ev.drop(y, lvl))))
+        p = ev.mul_rescale(ev.drop(x, lvl), ev.drop(y, lvl), times2=True)
         if a == b:
             return ev.add_const(p, -1.0)
         return ev.sub(p, ev.to_level_scale(T[abs(a - b)], p.level, p.scale))
@@ -254,7 +254,7 @@ class ChebyshevEvaluator:
         elif qct is None:
             prod = None
         else:
-            prod = ev.rescale(ev.mul(qct, Th))
+            prod = ev.mul_rescale(qct, Th)
         if prod is None:
             return rct
         if rct is None:

@@ -110,10 +110,14 @@ class EvaluatorBase:
             total = inner if total is None else self.add(total, inner)
         return total
 
+    def mul_rescale(self, a, b, times2=False):
+        """rescale(a * b) (times 2): back ends may merge relinearisation and rescale into one division"""
+        t = self.mul(a, b)
+        return self.rescale(self.double(t) if times2 else t)
+
     def square_double_minus_one(self, a):
         """2a^2 - 1 (a Chebyshev doubling / a cosine double angle), one level"""
-        t = self.rescale(self.double(self.mul(a, a)))
-        return self.add_const(t, -1.0)
+        return self.add_const(self.mul_rescale(a, a, times2=True), -1.0)
 
 
 # =================================================================================================
@@ -128,6 +132,7 @@ class GpuEvaluator(EvaluatorBase):
         self.pha, self.ctx, self.sk = pha, ctx, sk
         self.double_hoisting = double_hoisting
         self.concurrent_pairs = __import__("os").environ.get("PHA_CONCURRENT_PAIRS", "1") != "0"
+        self.merged_rescale = __import__("os").environ.get("PHA_MERGED_RESCALE", "1") != "0"
         # double hoisting makes a baby step (one inner product) several times cheaper than a giant step (moddown +
         # modup + inner product): bootstrap.DiagonalTransform shifts its split towards more baby steps by 2^baby_bias
         # (measured at N = 2^16 full slots, 4 levels per transform: bias 0 / 1 / 2 / 3 = 31.3 / 30.5 / 29.9 / 31.0 ms with
@@ -240,6 +245,15 @@ class GpuEvaluator(EvaluatorBase):
         self.ctx.multiply_and_relin_inplace(a.level, d, b.data, self.rlk)
         return Ct(d[:2], a.level, a.scale * b.scale)
 
+    def mul_rescale(self, a, b, times2=False):
+        """one C-ABI call: pha_multiply_relin_rescale (the key-switched part and the lifted tensor polys are divided by
+        P * q_last in a single moddown)"""
+        if not self.merged_rescale:
+            return super().mul_rescale(a, b, times2)
+        assert a.level == b.level
+        out = self.ctx.multiply_relin_rescale(a.level, a.data, b.data, self.rlk, times2)
+        return Ct(out, a.level + 1, a.scale * b.scale / self.q_last(a.level))
+
     def rescale(self, a):
         import torch
         out = torch.empty((2, self.limbs(a.level) - 1, self.n), dtype=torch.int64, device=a.data.device)
@@ -299,6 +313,7 @@ class GpuEvaluator(EvaluatorBase):
             sib.ctx = self.pha.PhantomContext(self.ctx.log_n, self.ctx.moduli, self.ctx.size_P)
             sib._seed, sib._mono = self._seed + (1 << 20), {}
             sib.double_hoisting, sib.baby_bias = self.double_hoisting, self.baby_bias
+            sib.merged_rescale, sib.concurrent_pairs = self.merged_rescale, False
             sib.stream, sib._sibling = torch.cuda.Stream(), None
             self._sibling = sib
         return self._sibling

@@ -108,6 +108,15 @@ struct LevelTool {
     std::vector<DevBuf<uint32_t>> modup_obase_tidx;      // per digit: table index of each output limb
     DevBuf<uint64_t> moddown_matrix;
     DevBuf<uint32_t> moddown_obase_tidx;
+    // merged relinearise + rescale: division by B = {q_{l-1}} u P in one moddown (built on first use)
+    struct MergedDown {
+        bool ready = false;
+        ShoupVec BHatInv;              // [alpha + 1], buffer order: q_{l-1}, then P
+        DevBuf<uint64_t> matrix;       // [size_Ql - 1][alpha + 2]: BHat_b mod q_j, then (-prod B) mod q_j
+        DevBuf<double> inv_b;          // [alpha + 1]: 1.0 / b
+        DevBuf<uint32_t> obase_tidx;   // [size_Ql - 1]
+        ShoupVec BInv, BInv2;          // [size_Ql - 1]: (prod B)^-1 mod q_j, and twice that
+    } merged;
     bool uniform_digits = false;                         // alpha divides size_Ql: one launch for all digits
     DevBuf<uint64_t> modup_matrix_all;
     DevBuf<uint32_t> modup_tidx_all;
@@ -585,6 +594,88 @@ int do_moddown(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *cx, uint
     ep.out_poly_stride = size_Ql * n;
     ep.sub_poly_stride = size_QlP * n;
     return ntt_forward(ctx, delta, polys, size_Ql * n, rq, addend ? EPI_SUB_MUL_ADD : EPI_SUB_MUL, ep, st);
+}
+
+// Division of `polys` polynomials over Q_l u P by B = {q_{l-1}} u P in one moddown: out[polys][l-1][n] =
+// (cx - [cx]_B) / prod(B) (x 2 when times2) with [.]_B the CENTRED remainder from an exact base conversion
+// (bconv_centred_kernel): rounding to nearest, where moddown_from_NTT + rescale_to_next leave up to alpha units of
+// conversion overflow and a floor.
+// This is rescale_to_next o moddown merged: one NTT pass over the ciphertext instead of two, no separate
+// INTT / broadcast of the last limb.  cx's limbs l-1 .. l+alpha-1 are destroyed; delta = scratch [polys][l-1][n].
+int build_merged_down(pha_context *ctx, LevelTool *lt) {
+    if (lt->merged.ready) return PHA_OK;
+    const size_t size_Ql = lt->size_Ql, alpha = ctx->size_P, nb = alpha + 1, out_l = size_Ql - 1;
+    const uint64_t *Q = ctx->moduli.data();
+    std::vector<uint64_t> B;
+    B.push_back(Q[size_Ql - 1]);
+    for (size_t k = 0; k < alpha; k++) B.push_back(Q[ctx->size_Q + k]);
+    if (nb + 1 > 16) return fail(PHA_ERR_INVALID_ARGUMENT, "the merged rescale supports up to 14 special primes");
+    std::vector<uint64_t> hat_inv(nb), matrix(out_l * (nb + 1)), binv(out_l), binv2(out_l);
+    std::vector<double> inv_b(nb);
+    for (size_t b = 0; b < nb; b++) {
+        hat_inv[b] = inv_mod_prime(product_mod_except(B.data(), 0, nb, b, B[b]), B[b]);
+        inv_b[b] = 1.0 / static_cast<double>(B[b]);
+    }
+    for (size_t j = 0; j < out_l; j++) {
+        for (size_t b = 0; b < nb; b++) matrix[j * (nb + 1) + b] = product_mod_except(B.data(), 0, nb, b, Q[j]);
+        const uint64_t prod = product_mod_except(B.data(), 0, nb, SIZE_MAX, Q[j]);
+        matrix[j * (nb + 1) + nb] = prod ? Q[j] - prod : 0;  // the column of the overflow count
+        binv[j] = inv_mod_prime(prod, Q[j]);
+        binv2[j] = (binv[j] * 2) % Q[j];
+    }
+    HIP_TRY(lt->merged.inv_b.upload(inv_b));
+    std::vector<uint32_t> tidx(out_l);
+    for (size_t j = 0; j < out_l; j++) tidx[j] = static_cast<uint32_t>(j);
+    HIP_TRY(lt->merged.BHatInv.upload(hat_inv, B.data()));
+    HIP_TRY(lt->merged.matrix.upload(matrix));
+    HIP_TRY(lt->merged.obase_tidx.upload(tidx));
+    HIP_TRY(lt->merged.BInv.upload(binv, Q));
+    HIP_TRY(lt->merged.BInv2.upload(binv2, Q));
+    lt->merged.ready = true;
+    return PHA_OK;
+}
+
+int do_merged_moddown(pha_context *ctx, LevelTool *lt, uint64_t *out, uint64_t *cx, uint64_t *delta, size_t polys, bool times2,
+                      hipStream_t st) {
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, alpha = ctx->size_P, size_QlP = size_Ql + alpha, out_l = size_Ql - 1;
+    if (size_Ql < 2) return fail(PHA_ERR_INVALID_ARGUMENT, "end of modulus switching chain reached");
+    PHA_TRY(build_merged_down(ctx, lt));
+    NttRange rb;
+    PHA_TRY(make_range(ctx, alpha + 1, out_l, ctx->size_QP, alpha, 0, 0, rb));
+    Epilogue ep{};
+    ep.cst = lt->merged.BHatInv.v.p - out_l;  // indexed by absolute buffer limb
+    ep.cst_shoup = lt->merged.BHatInv.s.p - out_l;
+    PHA_TRY(ntt_backward(ctx, cx, cx, polys, size_QlP * n, rb, EPI_SCALE, ep, st));
+    {   // exact, centred base conversion B -> Q_{l-1} (bconv_centred_kernel): the division below rounds to nearest
+        const uint32_t n32 = static_cast<uint32_t>(n), obase = static_cast<uint32_t>(out_l);
+        const uint32_t base_wgs = (n32 / 256) * static_cast<uint32_t>(polys);
+        const uint32_t groups = std::min<uint32_t>(obase, std::max<uint32_t>(1, (4096u + base_wgs - 1) / base_wgs));
+        const uint32_t lpb = (obase + groups - 1) / groups;
+        const dim3 grid(n32 / 256, (obase + lpb - 1) / lpb, static_cast<uint32_t>(polys));
+#define CENTRED_CASE(IB)                                                                                                  \
+    case IB:                                                                                                              \
+        hipLaunchKernelGGL((bconv_centred_kernel<IB>), grid, dim3(256), 0, st, delta, cx + out_l * n, lt->merged.matrix.p, \
+                           lt->merged.inv_b.p, ctx->d_mod.p, lt->merged.obase_tidx.p, obase, lpb, n32, out_l * n,          \
+                           size_QlP * n);                                                                                 \
+        break;
+        switch (alpha + 1) {
+            CENTRED_CASE(2) CENTRED_CASE(3) CENTRED_CASE(4) CENTRED_CASE(5) CENTRED_CASE(6) CENTRED_CASE(7) CENTRED_CASE(8)
+            CENTRED_CASE(9) CENTRED_CASE(10) CENTRED_CASE(11) CENTRED_CASE(12) CENTRED_CASE(13) CENTRED_CASE(14) CENTRED_CASE(15)
+            default: return fail(PHA_ERR_INVALID_ARGUMENT, "the merged rescale supports 1 to 14 special primes");
+        }
+#undef CENTRED_CASE
+        PHA_TRY(check_launch("bconv_centred"));
+    }
+    NttRange rq;
+    PHA_TRY(make_range(ctx, out_l, 0, 0, 0, 0, 0, rq));
+    Epilogue e2{};
+    e2.out = out;
+    e2.sub = cx;
+    e2.cst = times2 ? lt->merged.BInv2.v.p : lt->merged.BInv.v.p;
+    e2.cst_shoup = times2 ? lt->merged.BInv2.s.p : lt->merged.BInv.s.p;
+    e2.out_poly_stride = out_l * n;
+    e2.sub_poly_stride = size_QlP * n;
+    return ntt_forward(ctx, delta, polys, out_l * n, rq, EPI_SUB_MUL, e2, st);
 }
 
 // addend (default ct itself) is what the switched key part is added to; addend_every as in Epilogue
@@ -1859,6 +1950,47 @@ int pha_apply_galois_batched(pha_context *ctx, size_t chain_index, const uint64_
     PHA_TRY(do_modup_batched(ctx, lt, t_mod_up, out + size_Ql * n, t_cks + size_Ql * n, ct_words, batch, st));
     PHA_TRY(do_inner_prod_batched(ctx, lt, cx, t_mod_up, galois_evks, batch, st));
     return do_moddown(ctx, lt, out, cx, delta, out, 2 * batch, st, 2);  // first polys += pi(c0), second polys as they come
+}
+
+// HMult + relinearise + rescale as one composite (and optionally x 2, the doubling of a Chebyshev product):
+// out[2][l-1][N] = ((P * (d0, d1) + KS_QP(d2)) / (P * q_{l-1})), (d0, d1, d2) = ct1 (x) ct2.  The key-switched part
+// stays over Q_l u P, the tensor's first two polys are lifted onto it, and ONE moddown divides by the special primes
+// and the level's last prime together.  Against multiply + relinearize + rescale_to_next it saves a full NTT pass
+// over the ciphertext, the INTT of the last limb and its broadcast; the result differs by rounding only
+// (both are within a few units of the exact quotient).
+int pha_multiply_relin_rescale(pha_context *ctx, size_t chain_index, const uint64_t *ct1, const uint64_t *ct2,
+                               const uint64_t *const *relin_evks, uint64_t *out, int times2, pha_stream_t stream) {
+    REQUIRE_CTX(ct1 && ct2 && relin_evks && out);
+    LevelTool *lt;
+    PHA_TRY(get_level(ctx, chain_index, &lt));
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, size_QlP = size_Ql + ctx->size_P;
+    if (size_Ql < 2) return fail(PHA_ERR_INVALID_ARGUMENT, "end of modulus switching chain reached");
+    hipStream_t st = as_stream(stream);
+    if (!ctx->d_bigP_mod_q.p) {
+        LevelConstants lc;
+        build_level_constants(ctx->moduli, ctx->size_P, ctx->size_Q, lc);
+        HIP_TRY(ctx->d_bigP_mod_q.upload(lc.bigP_mod_q));
+    }
+    uint64_t *ws;
+    PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 5 * size_Ql) * n, &ws));
+    uint64_t *t_mod_up = ws, *cx = t_mod_up + lt->beta * size_QlP * n, *scratch = cx + 2 * size_QlP * n, *d = scratch + 2 * size_Ql * n;
+    {   // tensor product, doubled here when asked: before the division the doubling is exact
+        const dim3 tg(static_cast<uint32_t>(size_Ql) * (static_cast<uint32_t>(n) / 512));
+        if (ct1 == ct2)
+            hipLaunchKernelGGL((tensor_prod_2x2_kernel<true>), tg, dim3(256), 0, st, ct1, ct1, ctx->d_mod.p, d, static_cast<uint32_t>(n),
+                               static_cast<uint32_t>(size_Ql), times2 ? 1u : 0u);
+        else
+            hipLaunchKernelGGL((tensor_prod_2x2_kernel<false>), tg, dim3(256), 0, st, ct1, ct2, ctx->d_mod.p, d, static_cast<uint32_t>(n),
+                               static_cast<uint32_t>(size_Ql), times2 ? 1u : 0u);
+        PHA_TRY(check_launch("tensor_prod_2x2"));
+    }
+    PHA_TRY(do_modup(ctx, lt, t_mod_up, d + 2 * size_Ql * n, scratch, st));
+    PHA_TRY(do_inner_prod(ctx, lt, cx, t_mod_up, relin_evks, st));
+    const uint32_t n32 = static_cast<uint32_t>(n), ql = static_cast<uint32_t>(size_Ql), qlp = static_cast<uint32_t>(size_QlP);
+    hipLaunchKernelGGL((lift_qp_kernel<false>), dim3(qlp * (n32 / 512), 2), dim3(256), 0, st, cx, d, static_cast<const uint32_t *>(nullptr),
+                       ctx->d_bigP_mod_q.p, ctx->d_mod.p, n32, ql, qlp);
+    PHA_TRY(check_launch("lift_qp"));
+    return do_merged_moddown(ctx, lt, out, cx, scratch, 2, false, st);
 }
 
 // ---- bootstrapping primitives (src/boot/Bootstrapper.cu) ------------------------------------------

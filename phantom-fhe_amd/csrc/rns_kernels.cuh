@@ -94,6 +94,44 @@ __global__ __launch_bounds__(256) void bconv_matmul_kernel(uint64_t *__restrict_
     }
 }
 
+// Base conversion with the overflow corrected and the remainder centred (Halevi-Polyakov-Shoup): besides the IB
+// residues y_i < b_i the lane forms e = rint(sum_i y_i / b_i) in FP64 — the number of times prod(b) must be taken off
+// sum_i y_i * BHat_i for the CENTRED remainder — and feeds it to the dot product as an extra input against the
+// matrix column (-prod(b)) mod q_j.  The conversion is then exact (a quotient built on it is rounded to nearest:
+// error <= 1/2 instead of up to IB units of overflow plus the floor's bias), except when sum_i y_i / b_i falls within
+// ~IB * 2^-53 of a half-integer, where e may be off by one (one unit of error, probability ~2^-49 per coefficient).
+// inv_b[i] = 1.0 / b_i; products and sums in this order, no contraction: the oracle's restatement does the same.
+template <int IB>
+__global__ __launch_bounds__(256) void bconv_centred_kernel(uint64_t *__restrict__ dst, const uint64_t *__restrict__ y,
+                                                            const uint64_t *__restrict__ matrix /* [obase][IB + 1] */,
+                                                            const double *__restrict__ inv_b,
+                                                            const DModulus *__restrict__ obase_mod,
+                                                            const uint32_t *__restrict__ obase_tidx, uint32_t obase_size,
+                                                            uint32_t limbs_per_block, uint32_t n, size_t dst_stride,
+                                                            size_t y_stride) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    dst += blockIdx.z * dst_stride;
+    y += blockIdx.z * y_stride;
+    uint64_t in[IB + 1];
+    double v = 0.0;
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int i = 0; i < IB; i++) {
+            in[i] = y[static_cast<size_t>(i) * n + k];
+            const double t = static_cast<double>(in[i]) * inv_b[i];
+            v = v + t;
+        }
+    }
+    in[IB] = static_cast<uint64_t>(__builtin_rint(v));
+    const uint32_t j0 = blockIdx.y * limbs_per_block;
+    const uint32_t j1 = min(j0 + limbs_per_block, obase_size);
+    for (uint32_t j = j0; j < j1; j++) {
+        const u128_t acc = dot_residues<IB + 1>(in, matrix + static_cast<size_t>(j) * (IB + 1));
+        dst[static_cast<size_t>(j) * n + k] = barrett128(acc, obase_mod[obase_tidx[j]]);
+    }
+}
+
 // generic fallback for ibase sizes without an instantiation
 __global__ __launch_bounds__(256) void bconv_matmul_generic_kernel(uint64_t *dst, const uint64_t *y,
                                                                    const uint64_t *matrix, const DModulus *obase_mod,
@@ -372,7 +410,8 @@ __global__ __launch_bounds__(256) void apply_galois_ntt_kernel(uint64_t *dst, co
 template <bool SQUARE>
 __global__ __launch_bounds__(256) void tensor_prod_2x2_kernel(const uint64_t *op1, const uint64_t *op2,
                                                               const DModulus *mod, uint64_t *res, uint32_t n,
-                                                              uint32_t limbs) {
+                                                              uint32_t limbs, uint32_t times2 = 0) {
+    // times2: (2 d0, 2 d1, 2 d2) — the doubling of a Chebyshev product taken BEFORE any division, where it is exact
     const uint32_t per_limb = n / 512;
     const uint32_t l = blockIdx.x / per_limb;
     const size_t id = static_cast<size_t>(l) * n + ((blockIdx.x % per_limb) * 256 + threadIdx.x) * 2;
@@ -393,6 +432,11 @@ __global__ __launch_bounds__(256) void tensor_prod_2x2_kernel(const uint64_t *op
     uint64_t ty = mul_barrett(a0.y + a1.y, b0.y + b1.y, m) + 2 * q - d0.y - d2.y;
     d1.x = csub(csub(tx, q), q);
     d1.y = csub(csub(ty, q), q);
+    if (times2) {
+        d0 = ulonglong2{csub(d0.x + d0.x, q), csub(d0.y + d0.y, q)};
+        d1 = ulonglong2{csub(d1.x + d1.x, q), csub(d1.y + d1.y, q)};
+        d2 = ulonglong2{csub(d2.x + d2.x, q), csub(d2.y + d2.y, q)};
+    }
     *reinterpret_cast<ulonglong2 *>(res + id) = d0;
     *reinterpret_cast<ulonglong2 *>(res + id + rc) = d1;
     *reinterpret_cast<ulonglong2 *>(res + id + 2 * rc) = d2;

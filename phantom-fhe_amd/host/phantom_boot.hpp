@@ -238,6 +238,15 @@ public:
         d.set_scale(a.scale() * b.scale());
         return d;
     }
+    // rescale(relinearize(a * b)) (x 2) as ONE composite: pha_multiply_relin_rescale divides the key-switched part and
+    // the lifted tensor polys by P * q_last in a single, rounded-to-nearest moddown
+    PhantomCiphertext mul_rescale(const PhantomCiphertext &a, const PhantomCiphertext &b, bool times2 = false) {
+        if (a.chain_index() != b.chain_index()) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+        PhantomCiphertext d = make(a.chain_index() + 1, a.scale() * b.scale() / q_last(a.chain_index()));
+        check(pha_multiply_relin_rescale(h(), a.chain_index(), a.data(), b.data(), relin_keys->public_keys_ptr(), d.data(),
+                                         times2 ? 1 : 0, s()));
+        return d;
+    }
     PhantomCiphertext rescale(const PhantomCiphertext &a) {
         PhantomCiphertext d = make(a.chain_index() + 1, a.scale() / q_last(a.chain_index()));
         check(pha_rescale_to_next(h(), a.chain_index(), a.data(), 2, d.data(), s()));
@@ -280,11 +289,7 @@ public:
         return rescale(mul_const(x, 1.0, sc * q_last(level - 1) / x.scale()));
     }
     // 2a^2 - 1: a Chebyshev doubling / a cosine double angle, one level
-    PhantomCiphertext square_double_minus_one(const PhantomCiphertext &a) {
-        PhantomCiphertext t = mul(a, a);
-        add_inplace(t, t);
-        return add_const(rescale(t), -1.0);
-    }
+    PhantomCiphertext square_double_minus_one(const PhantomCiphertext &a) { return add_const(mul_rescale(a, a, true), -1.0); }
 
     // ---- rotations ---------------------------------------------------------------------------------------
     uint32_t elt(int step) const {
@@ -514,9 +519,7 @@ class ChebyshevEvaluator {
         const PhantomCiphertext &x = T_.at(a), &y = T_.at(b);
         const size_t lvl = std::max(x.chain_index(), y.chain_index());
         PhantomCiphertext tx, ty;
-        PhantomCiphertext p = ev_->mul(ev_->at_level(x, lvl, tx), ev_->at_level(y, lvl, ty));
-        ev_->add_inplace(p, p);
-        p = ev_->rescale(p);
+        PhantomCiphertext p = ev_->mul_rescale(ev_->at_level(x, lvl, tx), ev_->at_level(y, lvl, ty), true);
         if (a == b) return ev_->add_const(p, -1.0);
         return ev_->sub(p, ev_->to_level_scale(T_.at(std::abs(a - b)), p.chain_index(), p.scale()));
     }
@@ -582,7 +585,7 @@ class ChebyshevEvaluator {
             prod.ct = ev_->rescale(ev_->mul_const(Th, qv.c, qscale));
         } else if (qv.kind == Val::CT) {
             prod.kind = Val::CT;
-            prod.ct = ev_->rescale(ev_->mul(qv.ct, Th));
+            prod.ct = ev_->mul_rescale(qv.ct, Th);
         }
         if (prod.kind == Val::NONE) return rv;
         if (rv.kind == Val::NONE) return prod;

@@ -315,6 +315,30 @@ def test_batched_rotation_equals_one_by_one(gpu, pha, orc, size_p, chain_index, 
     ctx.close()
 
 
+@pytest.mark.parametrize("size_p,chain_index", [(2, 1), (2, 3), (1, 2), (3, 1)])
+def test_merged_multiply_relin_rescale(gpu, pha, orc, size_p, chain_index):
+    """pha_multiply_relin_rescale against its restatement from the oracle's primitives (bit-exact), product and
+    square, with and without the doubling"""
+    from oracle.ckks_ref import multiply_relin_rescale_ref
+    mods = orc.coeff_modulus_create(4096, [45] * 6 + [55] * size_p)
+    ctx, o = pha.PhantomContext(12, mods, size_p), orc.Oracle(12, mods, size_p)
+    size_ql = ctx.size_Ql(chain_index)
+    tq = list(range(size_ql))
+    a = np.stack([o.uniform_poly(tq, 701), o.uniform_poly(tq, 702)])
+    b = np.stack([o.uniform_poly(tq, 703), o.uniform_poly(tq, 704)])
+    evk_h, evk_d = _uniform_evk(pha, o, 710)
+    d_a, d_b = _dev(pha, a), _dev(pha, b)
+    for times2 in (False, True):
+        out = ctx.multiply_relin_rescale(chain_index, d_a, d_b, evk_d, times2)
+        assert (_host(pha, out) == multiply_relin_rescale_ref(o, size_ql, a, b, evk_h, times2)).all()
+    out = ctx.multiply_relin_rescale(chain_index, d_a, d_a, evk_d, True)          # square
+    assert (_host(pha, out) == multiply_relin_rescale_ref(o, size_ql, a, a, evk_h, True)).all()
+    assert (_host(pha, d_a) == a).all() and (_host(pha, d_b) == b).all()           # operands preserved
+    with pytest.raises(pha.PhantomError):
+        ctx.multiply_relin_rescale(ctx.size_Q, d_a[:, :1].contiguous(), d_a[:, :1].contiguous(), evk_d)
+    ctx.close()
+
+
 def test_bad_chain_index(gpu, pha, small):
     ctx, o = small
     import torch
