@@ -173,18 +173,24 @@ class ChebyshevEvaluator:
     rescaled product land on the target (Paterson-Stockmeyer over the Chebyshev basis:
     p = q * T_h + r with T_j = 2 T_{j-h} T_h - T_{2h-j})."""
 
-    def __init__(self, ev, coeffs, baby_log=2):
+    def __init__(self, ev, coeffs, baby_log=2, optimal_depth=False):
+        """optimal_depth: ceil(log2(d+1)) levels instead of one more.  The leaves c1 T1 + c2 T2 + c3 T3 are computed as
+        (c1 - c3) T1 + c2 T2 + (2 c3 T1) T2, the constant riding on T1 one level above T2: T3 is never formed and a
+        leaf ends at the level of T3 itself, at the price of one ciphertext product per leaf (the approximate ReLU
+        of cnn.py, whose three polynomials would otherwise cost three more levels)."""
         self.ev = ev
         self.c = np.array(coeffs, dtype=np.float64)
         d = len(self.c) - 1
-        self.m = max(1, math.ceil(math.log2(d + 1)))
+        self.m = max(2 if optimal_depth else 1, math.ceil(math.log2(d + 1)))
         self.l = min(baby_log, self.m)
-        self.depth = self.m + 1
+        self.optimal = optimal_depth
+        assert not optimal_depth or self.l == 2
+        self.depth = self.m if optimal_depth else self.m + 1
 
     def _powers(self, w):
         ev = self.ev
         T = {1: w}
-        for j in range(2, 1 << self.l):          # babies T_2 .. T_{2^l - 1}
+        for j in range(2, 3 if self.optimal else 1 << self.l):          # babies T_2 .. T_{2^l - 1}
             a = 1 << (j.bit_length() - 1)
             T[j] = self._product(T, j // 2, j // 2) if j == a else self._product(T, a, j - a)
         for k in range(self.l, self.m):          # giants T_{2^l} .. T_{2^(m-1)}
@@ -217,6 +223,12 @@ class ChebyshevEvaluator:
         lvl = level - 1
         q = ev.q_last(lvl)
         acc = None
+        if self.optimal and len(c) > 3 and abs(c[3]) >= 1e-300:
+            # (2 c3 T1) T2, unrescaled at (lvl, scale * q); T3 = 2 T1 T2 - T1 puts -c3 on T1
+            t1, t2 = ev.drop(self.T[1], lvl - 1), ev.drop(self.T[2], lvl)
+            a = ev.rescale(ev.mul_const(t1, 2.0 * c[3], (scale * q / t2.scale) * ev.q_last(lvl - 1) / t1.scale))
+            acc = ev.mul(a, t2)
+            c = np.array([c[0], c[1] - c[3], c[2]])
         for j in range(1, len(c)):
             if abs(c[j]) < 1e-300:
                 continue
@@ -275,13 +287,13 @@ class Bootstrapper:
     parts go through EvalMod as two ciphertexts."""
 
     def __init__(self, ev, K=12, r=3, degree=31, delta=2.0 ** 40, baby_log=2, packed=None,
-                 transform="dense", c2s_groups=3, s2c_groups=3, msg_scale=None):
+                 transform="dense", c2s_groups=3, s2c_groups=3, msg_scale=None, slots=None):
         """delta: the scale EvalMod works at (its primes should be close to it); msg_scale: the scale of
         the ciphertexts to refresh (default delta).  A delta well above msg_scale (say 2^58 against 2^46)
         lowers the EvalMod noise floor, which full slots see amplified by sqrt(s) * q0 / (2 pi msg_scale)."""
         self.ev, self.K, self.r, self.delta = ev, K, r, delta
         self.msg_scale = delta if msg_scale is None else msg_scale
-        s, n = ev.s, ev.n
+        s, n = (ev.s if slots is None else slots), ev.n      # slots: several packings on one evaluator (cnn.py)
         self.s = s
         self.transform = transform
         assert transform in ("dense", "fft")

@@ -142,6 +142,7 @@ class GpuEvaluator(EvaluatorBase):
         self.rlk = ctx.gen_relinkey(sk, self._next_seed())
         self.galois = {}
         self._mono = {}
+        self.auto_keys = False               # generate a missing rotation key on first use (cnn.py: hundreds of steps)
 
     def _next_seed(self):
         self._seed += 1
@@ -272,6 +273,8 @@ class GpuEvaluator(EvaluatorBase):
         live = [s for s in steps if s % half]
         outs = {}
         if live:
+            if self.auto_keys:
+                self.add_rotation_keys(live, conj=False)
             elts = [self.elt(s) for s in live]
             res = self.ctx.rotate_hoisted(a.level, a.data, elts, [self.galois[e] for e in elts])
             outs = {s: Ct(r, a.level, a.scale) for s, r in zip(live, res)}
@@ -311,7 +314,7 @@ class GpuEvaluator(EvaluatorBase):
             EvaluatorBase.__init__(sib, self.log_n, self.q, self.s)
             sib.pha, sib.sk, sib.rlk, sib.galois = self.pha, self.sk, self.rlk, self.galois
             sib.ctx = self.pha.PhantomContext(self.ctx.log_n, self.ctx.moduli, self.ctx.size_P)
-            sib._seed, sib._mono = self._seed + (1 << 20), {}
+            sib._seed, sib._mono, sib.auto_keys = self._seed + (1 << 20), {}, False
             sib.double_hoisting, sib.baby_bias = self.double_hoisting, self.baby_bias
             sib.merged_rescale, sib.concurrent_pairs = self.merged_rescale, False
             sib.stream, sib._sibling = torch.cuda.Stream(), None
@@ -351,12 +354,17 @@ class SimEvaluator(EvaluatorBase):
         pass
 
     # encode / decode by the definition of the embedding (oracle-free: this module ships in the product)
+    _matrices = {}
+
     @staticmethod
     def _matrix(s):
-        m = 4 * s
-        rot = [pow(5, j, m) for j in range(s)]
-        e = np.array([[(r * k) % m for k in range(s)] for r in rot], dtype=np.float64)
-        return np.exp(2j * np.pi * e / m)
+        mat = SimEvaluator._matrices.get(s)
+        if mat is None:
+            m = 4 * s
+            rot = np.array([pow(5, j, m) for j in range(s)], dtype=np.int64)
+            e = (rot[:, None] * np.arange(s, dtype=np.int64)[None, :]) % m
+            mat = SimEvaluator._matrices[s] = np.exp(2j * np.pi * e / m)
+        return mat
 
     def encode(self, values, scale, level, sparse_slots=None):
         s = self.s if sparse_slots is None else sparse_slots
