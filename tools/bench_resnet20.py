@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Encrypted ResNet-20 / CIFAR-10 inference at N = 2^16 on one GPU (BASELINE config 5: bootstrapping driving the
+reference's examples/cnn.cu).  Pretrained parameters: tests/golden/resnet20_cifar10.npz (the reference's
+pretrained_parameters/resnet20_new); the image is synthetic (the reference's CIFAR-10 test file is not in its
+repository).  Checks the decrypted logits against the plain network (oracle/cnn_ref.py) and prints one JSON line.
+
+    python tools/bench_resnet20.py [--layers 20] [--reps 2] [--delta-bits 42] [--evalmod-bits 56]
+"""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import phantom_fhe_amd as pha
+from phantom_fhe_amd import cnn
+from phantom_fhe_amd.bootstrap import Bootstrapper
+from phantom_fhe_amd.ckks import GpuEvaluator
+from oracle import cnn_ref
+
+
+def smooth_image(seed, shape=(3, 32, 32)):
+    """a seeded low-frequency random field with the statistics of a normalised CIFAR-10 image (|pixel| < 2.5)"""
+    rng = np.random.default_rng(seed)
+    c, h, w = shape
+    f = np.fft.fft2(rng.normal(size=shape))
+    ky, kx = np.meshgrid(np.fft.fftfreq(h), np.fft.fftfreq(w), indexing="ij")
+    img = np.real(np.fft.ifft2(f / (1.0 + 40.0 * (kx ** 2 + ky ** 2) * h)))
+    img = img / img.std(axis=(1, 2), keepdims=True) + rng.normal(0.0, 0.3, (c, 1, 1))
+    return np.clip(img, -2.5, 2.5)
+
+
+def build(args):
+    relu = cnn.default_relu()
+    d, e, g = args.delta_bits, args.evalmod_bits, args.groups
+    q_bits = [d + 10] + [d] * (relu.depth + 2) + [d] * g + [e] * 10 + [min(60, d + 8)] * g
+    while len(q_bits) % args.alpha:
+        q_bits.insert(1, d)
+    n = 1 << args.log_n
+    mods = pha.coeff_modulus_create(n, q_bits + [60] * args.alpha)
+    ctx = pha.PhantomContext(args.log_n, mods, args.alpha)
+    sk = ctx.gen_secretkey(21, hamming_weight=192)
+    ev = GpuEvaluator(pha, ctx, sk, n // 2)
+    ev.auto_keys = True
+    boot = {}
+    for s in (n // 4, n // 8, n // 16):
+        boot[s] = Bootstrapper(ev, K=25, r=4, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d, transform="fft", c2s_groups=g, s2c_groups=g, slots=s)
+    return ctx, ev, boot, relu, mods
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log-n", type=int, default=16)
+    ap.add_argument("--layers", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--alpha", type=int, default=3)
+    ap.add_argument("--groups", type=int, default=3)
+    ap.add_argument("--delta-bits", type=int, default=42)
+    ap.add_argument("--evalmod-bits", type=int, default=56)
+    ap.add_argument("--image-seed", type=int, default=0)
+    ap.add_argument("--phases", action="store_true", help="synchronise after every block and print where the time goes")
+    args = ap.parse_args()
+    t0 = time.perf_counter()
+    ctx, ev, boot, relu, mods = build(args)
+    if args.layers == 20:
+        params = cnn.load_parameters_npz(os.path.join(ROOT, "tests", "golden", "resnet20_cifar10.npz"))
+    else:
+        params = cnn_ref.synthetic_parameters({8: 0, 14: 1, 32: 4}[args.layers], seed=1)
+    net = cnn.ResNetCifar10(ev, params, layer_num=args.layers, B=40.0, relu=relu, bootstrappers=boot)
+    image = smooth_image(args.image_seed)
+    level = ev.bottom - net.levels_after_bootstrap() - 2     # the first convolution comes before the first ReLU
+    x = net.encrypt_image(image, 2.0 ** args.delta_bits, level)
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    seen = {}
+    net.trace = lambda tag, t: seen.__setitem__(tag, net.B * cnn.unpack_tensor(np.real(ev.decrypt_decode(t.ct, 1 << t.logn)), t.k, t.h, t.w, t.c))
+    logits = net.decrypt_logits(net(x))                          # first run: encodes the constants, generates rotation keys
+    torch.cuda.synchronize()
+    first_s = time.perf_counter() - t0
+    net.trace = None
+    want_seen = {}
+    B = net.B
+    want = cnn_ref.resnet_cifar10(params, image, net.end_num, relu=lambda v: B * relu(v / B), trace=lambda tag, t: want_seen.__setitem__(tag, t))
+    exact = cnn_ref.resnet_cifar10(params, image, net.end_num)
+    block_err = {tag: float(np.abs(seen[tag] - want_seen[tag]).max()) for tag in want_seen}
+    times = []
+    for _ in range(args.reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = net(x)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    again = net.decrypt_logits(out)
+    key_bytes = sum(k.numel() * 8 for k in ev.galois.values()) if ev.galois and hasattr(next(iter(ev.galois.values())), "numel") else None
+    res = {"metric": "encrypted ResNet-%d CIFAR-10 inference ms" % args.layers, "value": 1e3 * min(times), "unit": "ms", "log_n": args.log_n,
+           "q_limbs": len(mods) - args.alpha, "special_primes": args.alpha, "log_qp": round(float(sum(np.log2(np.array(mods, dtype=np.float64)))), 1),
+           "delta_bits": args.delta_bits, "evalmod_bits": args.evalmod_bits, "bootstrappings": 6 * (net.end_num + 1),
+           "relu": {"degrees": list(relu.degrees), "alpha": round(relu.alpha, 2), "levels": relu.depth},
+           "logits": [round(float(v), 4) for v in logits], "logits_plain_same_relu": [round(float(v), 4) for v in want],
+           "max_logit_error_vs_plain_same_relu": float(np.abs(logits - want).max()), "max_logit_error_vs_exact_relu": float(np.abs(logits - exact).max()),
+           "argmax": int(np.argmax(logits)), "argmax_plain": int(np.argmax(exact)), "max_block_error": max(block_err.values()),
+           "max_activation_over_B": float(max(np.abs(v).max() for v in want_seen.values()) / B),
+           "repeat_logit_diff": float(np.abs(again - logits).max()),
+           "rotation_keys": len(ev.galois), "rotation_key_bytes": key_bytes, "encoded_constants": len(net.cache.store),
+           "setup_s": round(setup_s, 2), "first_inference_s": round(first_s, 2), "n_gpus": 1,
+           "data": "reference's pretrained ResNet-20 parameters, synthetic image" if args.layers == 20 else "synthetic parameters and image"}
+    if args.phases:
+        res["block_errors"] = block_err
+    print(json.dumps(res), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
