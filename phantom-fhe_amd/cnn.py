@@ -561,6 +561,30 @@ class ResNetCifar10:
         return fully_connected(ev, self.cache, "linear", x, self.params["linear_weight"], self.params["linear_bias"],
                                self.params["linear_bias"].size, self.widths[-1])
 
+    def capture(self, x):
+        """The whole inference as ONE HIP graph for inputs shaped like x (GPU back end): the convolutions and ReLUs
+        work on 1-17 limbs, kernels of a few microseconds that a host issuing them one by one cannot keep fed.
+        Returns run(x) -> TensorCipher; the result buffer is reused by the next run."""
+        import torch
+        from .ckks import Ct
+        static_in = TensorCipher(x.logn, x.k, x.h, x.w, x.c, x.t, x.p, Ct(x.ct.data.clone(), x.ct.level, x.ct.scale))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self(static_in)                      # constants encoded, keys generated, workspaces at their final size
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = self(static_in)
+
+        def run(y):
+            static_in.ct.data.copy_(y.ct.data)
+            graph.replay()
+            return static_out
+        run.graph = graph
+        return run
+
     def decrypt_logits(self, x):
         q = self.params["linear_bias"].size
         return np.real(self.ev.decrypt_decode(x.ct, 1 << x.logn)[:q])

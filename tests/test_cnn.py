@@ -177,3 +177,42 @@ def test_parameter_files(tmp_path):
     np.savez(tmp_path / "p.npz", **params)
     back = cnn.load_parameters_npz(str(tmp_path / "p.npz"))
     assert all(np.array_equal(back[k], params[k]) for k in params)
+
+
+@pytest.mark.gpu
+def test_resnet8_with_bootstrapping_on_the_gpu():
+    """N = 2^13, 8 x 8 images: three residual blocks, six bootstrappings (1024, 512 and 256 sparse slots), every
+    ciphertext operation through the C ABI; logits against the plain network with the same ReLU polynomial."""
+    import torch
+    from phantom_fhe_amd.bootstrap import Bootstrapper
+    from phantom_fhe_amd.ckks import GpuEvaluator
+    log_n, d, e, g, alpha = 13, 42, 56, 3, 4
+    relu = cnn.default_relu()
+    q_bits = [d + 10] + [d] * (relu.depth + 2) + [d] * g + [e] * 9 + [d + 8] * g
+    assert len(q_bits) % alpha == 0
+    n = 1 << log_n
+    mods = pha.coeff_modulus_create(n, q_bits + [60] * alpha)
+    ctx = pha.PhantomContext(log_n, mods, alpha)
+    sk = ctx.gen_secretkey(21, hamming_weight=32)
+    ev = GpuEvaluator(pha, ctx, sk, n // 2)
+    ev.auto_keys = True
+    boot = {s: Bootstrapper(ev, K=12, r=3, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d, transform="fft", c2s_groups=g, s2c_groups=g, slots=s)
+            for s in (n // 8, n // 16, n // 32)}
+    params = cnn_ref.synthetic_parameters(0, seed=3)
+    net = cnn.ResNetCifar10(ev, params, layer_num=8, B=16.0, relu=relu, image_shape=(3, 8, 8), bootstrappers=boot)
+    image = np.random.default_rng(3).normal(0.0, 1.0, (3, 8, 8))
+    x = net.encrypt_image(image, 2.0 ** d, ev.bottom - net.levels_after_bootstrap() - 2)
+    out = net(x)
+    assert out.ct.level == ev.bottom - net.levels_after_bootstrap() + relu.depth + 2      # average pooling and the linear layer: two levels
+    logits = net.decrypt_logits(out)
+    B = net.B
+    want = cnn_ref.resnet_cifar10(params, image, 0, relu=lambda v: B * relu(v / B))
+    exact = cnn_ref.resnet_cifar10(params, image, 0)
+    assert np.abs(logits - want).max() < 1e-2, (logits, want)
+    assert np.argmax(logits) == np.argmax(exact)
+    # one HIP graph of the whole inference gives the same ciphertext
+    run = net.capture(x)
+    again = net.decrypt_logits(run(x))
+    assert np.array_equal(again, logits)
+    torch.cuda.synchronize()
+    ctx.close()

@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--delta-bits", type=int, default=42)
     ap.add_argument("--evalmod-bits", type=int, default=56)
     ap.add_argument("--image-seed", type=int, default=0)
+    ap.add_argument("--graph", action="store_true", help="also capture the inference in one HIP graph and time its replay")
     ap.add_argument("--phases", action="store_true", help="synchronise after every block and print where the time goes")
     args = ap.parse_args()
     t0 = time.perf_counter()
@@ -103,8 +104,40 @@ def main():
            "rotation_keys": len(ev.galois), "rotation_key_bytes": key_bytes, "encoded_constants": len(net.cache.store),
            "setup_s": round(setup_s, 2), "first_inference_s": round(first_s, 2), "n_gpus": 1,
            "data": "reference's pretrained ResNet-20 parameters, synthetic image" if args.layers == 20 else "synthetic parameters and image"}
+    if args.graph:
+        t0 = time.perf_counter()
+        run = net.capture(x)
+        torch.cuda.synchronize()
+        res["graph_capture_s"] = round(time.perf_counter() - t0, 2)
+        gt = []
+        for _ in range(max(2, args.reps)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gout = run(x)
+            torch.cuda.synchronize()
+            gt.append(time.perf_counter() - t0)
+        res["graph_replay_ms"] = 1e3 * min(gt)
+        res["graph_logit_diff"] = float(np.abs(net.decrypt_logits(gout) - logits).max())
     if args.phases:
         res["block_errors"] = block_err
+        spent = {}
+
+        def timed(tag, fn):
+            def run(*a, **k):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                out = fn(*a, **k)
+                torch.cuda.synchronize()
+                spent[tag] = spent.get(tag, 0.0) + 1e3 * (time.perf_counter() - t)
+                return out
+            return run
+        for name, tag in (("multiplexed_parallel_convolution", "convolution"), ("multiplexed_parallel_batch_norm", "batch_norm"),
+                          ("approx_relu", "relu"), ("multiplexed_parallel_downsampling", "downsampling"), ("cnn_add", "add"),
+                          ("averagepooling_scale", "avgpool"), ("fully_connected", "linear")):
+            setattr(cnn, name, timed(tag, getattr(cnn, name)))
+        net._bootstrap = timed("bootstrap", net._bootstrap)
+        net(x)
+        res["phase_ms"] = {k: round(v, 2) for k, v in spent.items()}
     print(json.dumps(res), flush=True)
     ctx.close()
 
