@@ -214,6 +214,17 @@ def secondary_metrics(torch, pha):
                                           f"2^{d}, EvalMod at 2^{e}, {ev.limbs(out.level) - 1} levels left, log2(QP) = "
                                           f"{float(sum(np.log2(np.array(mods, dtype=np.float64)))):.0f}")
     ctx.close()
+    del ev, bs, ct, out
+
+    # BASELINE configs[4]: bootstrapping driving the ResNet-20 / CIFAR-10 example (tools/bench_resnet20.py: the
+    # reference's pretrained parameters, a synthetic image, logits checked against the plain network)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import bench_resnet20
+    rn = bench_resnet20.run(bench_resnet20.parse(["--reps", "2"]))
+    res["resnet20_cifar10_ms"] = rn["value"]
+    res["resnet20_cifar10_max_logit_error"] = rn["max_logit_error_vs_plain_same_relu"]
+    res["resnet20_cifar10_config"] = (f"N=2^16, {rn['q_limbs']} Q limbs + {rn['special_primes']} special primes, log2(QP) = {rn['log_qp']:.0f}, "
+                                      f"{rn['bootstrappings']} bootstrappings, ReLU degrees {rn['relu']['degrees']}, {rn['rotation_keys']} rotation keys")
     return res
 
 

@@ -187,8 +187,17 @@ class ChebyshevEvaluator:
         assert not optimal_depth or self.l == 2
         self.depth = self.m if optimal_depth else self.m + 1
 
+    def _at(self, j, level):
+        """T_j at `level` (dropping limbs copies the ciphertext: once per level)"""
+        key = (j, level)
+        t = self._dropped.get(key)
+        if t is None:
+            t = self._dropped[key] = self.ev.drop(self.T[j], level)
+        return t
+
     def _powers(self, w):
         ev = self.ev
+        self._dropped = {}
         T = {1: w}
         for j in range(2, 3 if self.optimal else 1 << self.l):          # babies T_2 .. T_{2^l - 1}
             a = 1 << (j.bit_length() - 1)
@@ -224,15 +233,20 @@ class ChebyshevEvaluator:
         q = ev.q_last(lvl)
         acc = None
         if self.optimal and len(c) > 3 and abs(c[3]) >= 1e-300:
-            # (2 c3 T1) T2, unrescaled at (lvl, scale * q); T3 = 2 T1 T2 - T1 puts -c3 on T1
-            t1, t2 = ev.drop(self.T[1], lvl - 1), ev.drop(self.T[2], lvl)
+            # (2 c3 T1) T2, T3 = 2 T1 T2 - T1 puts -c3 on T1
+            t1, t2 = self._at(1, lvl - 1), self._at(2, lvl)
             a = ev.rescale(ev.mul_const(t1, 2.0 * c[3], (scale * q / t2.scale) * ev.q_last(lvl - 1) / t1.scale))
-            acc = ev.mul(a, t2)
+            kappa = (c[1] - c[3]) / (2.0 * c[3])
+            if abs(c[2]) < 1e-300 and abs(kappa) <= 16.0:
+                # an odd leaf: (2 c3 T1) (T2 + kappa) is the whole of it, one merged product
+                out = ev.mul_rescale(a, ev.add_const(t2, kappa))
+                return ev.add_const(out, c[0]) if abs(c[0]) >= 1e-300 else out
+            acc = ev.mul(a, t2)                                  # unrescaled at (lvl, scale * q)
             c = np.array([c[0], c[1] - c[3], c[2]])
         for j in range(1, len(c)):
             if abs(c[j]) < 1e-300:
                 continue
-            t = ev.drop(self.T[j], lvl)
+            t = self._at(j, lvl)
             term = ev.mul_const(t, c[j], scale * q / t.scale)
             acc = term if acc is None else ev.add(acc, term)
         if acc is None:
@@ -258,7 +272,7 @@ class ChebyshevEvaluator:
         for j in range(h + 1, len(c)):
             qc[j - h] = 2.0 * c[j]
             r[2 * h - j] -= c[j]
-        Th = ev.drop(self.T[h], level - 1)
+        Th = self._at(h, level - 1)
         qct = self._eval(qc, k - 1, level - 1, scale * ev.q_last(level - 1) / Th.scale)
         rct = self._eval(r, k - 1, level, scale)
         if isinstance(qct, tuple):       # q is a constant: q*T_h is a plaintext multiple of T_h

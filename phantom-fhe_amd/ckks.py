@@ -83,6 +83,19 @@ class EvaluatorBase:
     def rotate(self, a, step):
         return self.rotate_many(a, [step])[0]
 
+    # ---- independent ciphertexts of one (level, scale) moved together (the q partial sums of a convolution) ---------
+    def batch(self, cts):
+        """one handle for several ciphertexts: `add` and `rotate_batch` act on all of them in one launch sequence"""
+        import numpy as _np
+        return Ct(_np.stack([c.data for c in cts]), cts[0].level, cts[0].scale)
+
+    def unbatch(self, b):
+        return [Ct(d, b.level, b.scale) for d in b.data]
+
+    def rotate_batch(self, b, step):
+        import numpy as _np
+        return Ct(_np.stack([self.rotate(c, step).data for c in self.unbatch(b)]), b.level, b.scale)
+
     # ---- two independent sub-circuits (the real and imaginary EvalMod of a full-slot bootstrap) -------------
     def run_pair(self, fa, fb):
         """(fa(ev_a), fb(ev_b)) for two evaluators that may run concurrently; here one after the other"""
@@ -173,6 +186,8 @@ class GpuEvaluator(EvaluatorBase):
         """one C-ABI call: pha_linear_transform_double_hoisted (one modup for the babies, one moddown per giant step)"""
         if not self.double_hoisting:
             return super().bsgs(a, baby_steps, giant_steps, plains)
+        if self.auto_keys:
+            self.add_rotation_keys(list(baby_steps) + list(giant_steps), conj=False)
         half = self.n // 2
         scale = next(p.scale for row in plains for p in row if p is not None)
         b_elts = [self.elt(s) if s % half else 1 for s in baby_steps]
@@ -204,7 +219,22 @@ class GpuEvaluator(EvaluatorBase):
 
     def add(self, a, b):
         self._same(a, b)
-        return Ct(self._binary(self.pha.lib().pha_add_rns_poly, a.data, b.data, 2, 2), a.level, a.scale)
+        polys = a.data.numel() // (a.data.shape[-2] * a.data.shape[-1])        # 2, or 2 * batch
+        assert a.data.shape == b.data.shape
+        return Ct(self._binary(self.pha.lib().pha_add_rns_poly, a.data, b.data, polys, polys), a.level, a.scale)
+
+    def batch(self, cts):
+        import torch
+        return Ct(torch.stack([c.data for c in cts]), cts[0].level, cts[0].scale)
+
+    def rotate_batch(self, b, step):
+        """pha_apply_galois_batched: one rotation of every ciphertext of the batch, kernels spanning the batch"""
+        if step % (self.n // 2) == 0:
+            return b
+        if self.auto_keys:
+            self.add_rotation_keys([step], conj=False)
+        e = self.elt(step)
+        return Ct(self.ctx.apply_galois_batched(b.level, b.data, e, self.galois[e]), b.level, b.scale)
 
     def sub(self, a, b):
         self._same(a, b)

@@ -84,12 +84,17 @@ class PlainCache:
     def __init__(self, ev):
         self.ev, self.store = ev, {}
 
-    def get(self, key, make, scale, level, slots):
-        full = (key, level, float(scale))
-        pt = self.store.get(full)
-        if pt is None:
-            pt = self.store[full] = self.ev.encode(np.asarray(make(), dtype=np.complex128), scale, level, slots)
-        return pt
+    def get(self, key, make, scale, level, slots, lt=False):
+        """lt: in the form `ev.bsgs` consumes (over Q_l u P on the GPU back end)"""
+        full = (key, level, float(scale), lt)
+        if full in self.store:
+            return self.store[full]
+        vec = make()                                     # None: an all-zero constant, nothing to multiply by
+        if vec is not None:
+            enc = self.ev.encode_lt if lt else self.ev.encode
+            vec = enc(np.asarray(vec, dtype=np.complex128), scale, level, slots)
+        self.store[full] = vec
+        return vec
 
 
 def _rot_steps(steps, n):
@@ -155,39 +160,45 @@ def multiplexed_parallel_convolution(ev, cache, name, x, co, st, fh, fw, data, r
     ocopy, oblk, o1, o2, ovalid = _coords(n, ko, ho, wo, to, 1)
     o_ch = ko * ko * oblk + ko * (o1 % ko) + o2 % ko
     bn_scale = constant_weight / np.sqrt(running_var + epsilon)
-    total = None
+    parts = []
     for i9 in range(q):
         out_ch = copy + pi * i9
         acc = None
         for (i1, i2), r in zip(taps, rots):
-            rr, cc = row + i1 - (fh - 1) // 2, col + i2 - (fw - 1) // 2
-            ok = valid & (out_ch < co) & (in_ch < ci) & (rr >= 0) & (rr < hi) & (cc >= 0) & (cc < wi)
-
-            def make(ok=ok, out_ch=out_ch, i1=i1, i2=i2):
-                return np.where(ok, W[np.minimum(out_ch, co - 1), np.minimum(in_ch, ci - 1), i1, i2], 0.0)
-            if not ok.any():
-                continue
-            acc = ev.mul_plain_add(acc, r, cache.get((name, "w", i9, i1, i2), make, ev.q_last(level), level, n))
-        var = ev.rescale(acc)
-        # summation over the input channels (cnn_phantom.cu:499-537)
-        for s in range(d):
-            var = ev.add(var, ev.rotate(var, (1 << s) % n))
-        for s in range(d):
-            var = ev.add(var, ev.rotate(var, ((1 << s) * ki * wi) % n))
-        if c == -1:
-            parts = ev.rotate_many(var, _rot_steps([ki * ki * hi * wi * s for s in range(1, ti)], n))
-            for part in parts:
-                var = ev.add(var, part)
-        else:
-            for s in range(c):
-                var = ev.add(var, ev.rotate(var, ((1 << s) * ki * ki * hi * wi) % n))
-        # collect the valid values into the output packing (cnn_phantom.cu:539-554)
+            def make(out_ch=out_ch, i1=i1, i2=i2):
+                rr, cc = row + i1 - (fh - 1) // 2, col + i2 - (fw - 1) // 2
+                ok = valid & (out_ch < co) & (in_ch < ci) & (rr >= 0) & (rr < hi) & (cc >= 0) & (cc < wi)
+                return np.where(ok, W[np.minimum(out_ch, co - 1), np.minimum(in_ch, ci - 1), i1, i2], 0.0) if ok.any() else None
+            pt = cache.get((name, "w", i9, i1, i2), make, ev.q_last(level), level, n)
+            if pt is not None:
+                acc = ev.mul_plain_add(acc, r, pt)
+        parts.append(ev.rescale(acc))
+    # summation over the input channels (cnn_phantom.cu:499-537): the q partial sums rotate by the same steps, so
+    # they move as one batch
+    var = ev.batch(parts)
+    sum_steps = [1 << s for s in range(d)] + [(1 << s) * ki * wi for s in range(d)]
+    if c != -1:
+        sum_steps += [(1 << s) * ki * ki * hi * wi for s in range(c)]
+    for step in sum_steps:
+        var = ev.add(var, ev.rotate_batch(var, step % n))
+    if c == -1:
+        acc = var
+        for s in range(1, ti):
+            acc = ev.add(acc, ev.rotate_batch(var, (ki * ki * hi * wi * s) % n))
+        var = acc
+    # collect the valid values into the output packing (cnn_phantom.cu:539-554): per partial sum one hoisted sum of
+    # masked rotations (one modup, one moddown)
+    total = None
+    for i9, v in enumerate(ev.unbatch(var)):
         js = [pi * i9 + i8 for i8 in range(pi) if pi * i9 + i8 < co]
-        steps = [(n // pi) * (j4 % pi) - j4 % ko - (j4 // (ko * ko)) * ko * ko * ho * wo - ((j4 % (ko * ko)) // ko) * ko * wo for j4 in js]
-        for j4, r in zip(js, ev.rotate_many(var, _rot_steps(steps, n))):
+        steps = _rot_steps([(n // pi) * (j4 % pi) - j4 % ko - (j4 // (ko * ko)) * ko * ko * ho * wo - ((j4 % (ko * ko)) // ko) * ko * wo for j4 in js], n)
+        plains = []
+        for j4 in js:
             def make_sel(j4=j4):
                 return np.where(ovalid & (o_ch == j4), bn_scale[j4], 0.0)
-            total = ev.mul_plain_add(total, r, cache.get((name, "sel", j4), make_sel, ev.q_last(level + 1), level + 1, n))
+            plains.append(cache.get((name, "sel", j4), make_sel, ev.q_last(level + 1), level + 1, n, lt=True))
+        part = ev.bsgs(v, steps, [0], [plains])
+        total = part if total is None else ev.add(total, part)
     out = ev.rescale(total)
     if not end:
         out = _double_copies(ev, out, n, po)

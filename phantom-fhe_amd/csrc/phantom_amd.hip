@@ -518,28 +518,31 @@ int do_inner_prod(pha_context *ctx, LevelTool *lt, uint64_t *cx, const uint64_t 
     return check_launch("key_switch_inner_prod");
 }
 
-// modup of `batch` ciphertexts' c2 at once (uniform digits, alpha > 1): cks / t_cks hold the b-th polynomial at
-// b * in_stride, dst is [batch][beta][size_QlP][n]
+// modup of `batch` ciphertexts' c2 at once (alpha > 1; uniform digits, or a single digit of size_Ql <= alpha limbs):
+// cks / t_cks hold the b-th polynomial at b * in_stride, dst is [batch][beta][size_QlP][n]
 int do_modup_batched(pha_context *ctx, LevelTool *lt, uint64_t *dst, const uint64_t *cks, uint64_t *t_cks, size_t in_stride,
                      size_t batch, hipStream_t st) {
     const size_t n = ctx->n, size_Ql = lt->size_Ql, alpha = ctx->size_P, size_QlP = size_Ql + alpha;
+    const bool single = !lt->uniform_digits;            // beta == 1: the digit is all of Q_l
+    const size_t len = single ? size_Ql : alpha;
     NttRange r;
     PHA_TRY(make_range(ctx, size_Ql, 0, 0, 0, 0, 0, r));
     Epilogue ep{};
     ep.cst = lt->partHatInv.v.p;
     ep.cst_shoup = lt->partHatInv.s.p;
     PHA_TRY(ntt_backward(ctx, t_cks, cks, batch, in_stride, r, EPI_SCALE, ep, st));
-    const uint32_t obase = static_cast<uint32_t>(size_QlP - alpha);
-    BconvBatch bt{size_QlP * n, alpha * n, static_cast<size_t>(obase) * alpha, obase, static_cast<uint32_t>(alpha), cks, alpha * n,
+    const uint32_t obase = static_cast<uint32_t>(size_QlP - len);
+    BconvBatch bt{size_QlP * n, len * n, static_cast<size_t>(obase) * len, obase, static_cast<uint32_t>(len), cks, len * n,
                   static_cast<uint32_t>(lt->beta), in_stride, in_stride};
-    PHA_TRY(launch_bconv(ctx, dst, t_cks, lt->modup_matrix_all.p, lt->modup_tidx_all.p, static_cast<uint32_t>(alpha), obase, 0,
-                         static_cast<uint32_t>(alpha), static_cast<uint32_t>(lt->beta * batch), bt, st));
+    PHA_TRY(launch_bconv(ctx, dst, t_cks, single ? lt->modup_matrix[0].p : lt->modup_matrix_all.p,
+                         single ? lt->modup_obase_tidx[0].p : lt->modup_tidx_all.p, static_cast<uint32_t>(len), obase, 0,
+                         static_cast<uint32_t>(len), static_cast<uint32_t>(lt->beta * batch), bt, st));
     NttRange rr;
     PHA_TRY(make_range(ctx, size_QlP, 0, ctx->size_QP, alpha, 0, 0, rr));
     rr.lm.digit_alpha = static_cast<uint32_t>(alpha);
     rr.lm.digit_limit = static_cast<uint32_t>(size_Ql);
     rr.lm.digit_count = static_cast<uint32_t>(lt->beta);
-    rr.active = rr.lm.active = static_cast<uint32_t>(size_QlP - alpha);
+    rr.active = rr.lm.active = static_cast<uint32_t>(size_QlP - len);
     return ntt_forward(ctx, dst, lt->beta * batch, size_QlP * n, rr, EPI_NONE, Epilogue{}, st);
 }
 
@@ -1927,7 +1930,7 @@ int pha_apply_galois_batched(pha_context *ctx, size_t chain_index, const uint64_
     hipStream_t st = as_stream(stream);
     const uint32_t *perm;
     PHA_TRY(get_galois_table(ctx, galois_elt, &perm));
-    if (!lt->uniform_digits) {  // alpha == 1 or a ragged last digit: one ciphertext at a time
+    if (!lt->uniform_digits && !(ctx->size_P > 1 && lt->beta == 1)) {  // alpha == 1 or several digits with a ragged last one: one ciphertext at a time
         for (size_t b = 0; b < batch; b++) {
             PHA_TRY(do_galois(ctx, in + b * ct_words, 2 * size_Ql, perm, out + b * ct_words, st));
             uint64_t *ws;

@@ -290,10 +290,11 @@ def test_double_hoisted_linear_transform(gpu, pha, orc, size_p, chain_index):
     ctx.close()
 
 
-@pytest.mark.parametrize("size_p,chain_index,batch", [(2, 1, 5), (2, 2, 3), (3, 1, 4), (1, 1, 3), (3, 3, 2)])
+@pytest.mark.parametrize("size_p,chain_index,batch", [(2, 1, 5), (2, 2, 3), (3, 1, 4), (1, 1, 3), (3, 3, 2), (3, 5, 4), (3, 6, 3), (2, 6, 5)])
 def test_batched_rotation_equals_one_by_one(gpu, pha, orc, size_p, chain_index, batch):
     """pha_apply_galois_batched = `batch` x pha_apply_galois_inplace, bit for bit (and so the oracle's result):
-    uniform digits take the batched kernels, alpha = 1 and a ragged last digit the per-ciphertext path."""
+    uniform digits and a single short digit (size_Ql < alpha) take the batched kernels, alpha = 1 and several digits
+    with a ragged last one the per-ciphertext path."""
     import torch
     mods = orc.coeff_modulus_create(4096, [45] * 6 + [55] * size_p)
     ctx, o = pha.PhantomContext(12, mods, size_p), orc.Oracle(12, mods, size_p)

@@ -31,7 +31,8 @@ def smooth_image(seed, shape=(3, 32, 32)):
 def build(args):
     relu = cnn.default_relu()
     d, e, g = args.delta_bits, args.evalmod_bits, args.groups
-    q_bits = [d + 10] + [d] * (relu.depth + 2) + [d] * g + [e] * 10 + [min(60, d + 8)] * g
+    g2 = args.s2c_groups or g
+    q_bits = [d + 10] + [d] * (relu.depth + 2) + [d] * g2 + [e] * 10 + [min(60, d + 8)] * g
     while len(q_bits) % args.alpha:
         q_bits.insert(1, d)
     n = 1 << args.log_n
@@ -42,23 +43,27 @@ def build(args):
     ev.auto_keys = True
     boot = {}
     for s in (n // 4, n // 8, n // 16):
-        boot[s] = Bootstrapper(ev, K=25, r=4, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d, transform="fft", c2s_groups=g, s2c_groups=g, slots=s)
+        boot[s] = Bootstrapper(ev, K=25, r=4, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d, transform="fft", c2s_groups=g, s2c_groups=g2, slots=s)
     return ctx, ev, boot, relu, mods
 
 
-def main():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--log-n", type=int, default=16)
     ap.add_argument("--layers", type=int, default=20)
     ap.add_argument("--reps", type=int, default=2)
-    ap.add_argument("--alpha", type=int, default=3)
-    ap.add_argument("--groups", type=int, default=3)
+    ap.add_argument("--alpha", type=int, default=4)
+    ap.add_argument("--groups", type=int, default=3, help="levels of CoeffToSlot")
+    ap.add_argument("--s2c-groups", type=int, default=2, help="levels of SlotToCoeff (0: --groups)")
     ap.add_argument("--delta-bits", type=int, default=42)
     ap.add_argument("--evalmod-bits", type=int, default=56)
     ap.add_argument("--image-seed", type=int, default=0)
     ap.add_argument("--graph", action="store_true", help="also capture the inference in one HIP graph and time its replay")
     ap.add_argument("--phases", action="store_true", help="synchronise after every block and print where the time goes")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def run(args):
     t0 = time.perf_counter()
     ctx, ev, boot, relu, mods = build(args)
     if args.layers == 20:
@@ -138,9 +143,40 @@ def main():
         net._bootstrap = timed("bootstrap", net._bootstrap)
         net(x)
         res["phase_ms"] = {k: round(v, 2) for k, v in spent.items()}
-    print(json.dumps(res), flush=True)
+        # evaluator methods inside the convolutions and the ReLUs (synchronised: sums exceed the phase times a little)
+        phase, inner, calls = [None], {}, {}
+
+        def scoped(tag, fn):
+            def run(*a, **k):
+                phase[0] = tag
+                try:
+                    return fn(*a, **k)
+                finally:
+                    phase[0] = None
+            return run
+
+        def method(name, fn):
+            def run(*a, **k):
+                if phase[0] is None:
+                    return fn(*a, **k)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                out = fn(*a, **k)
+                torch.cuda.synchronize()
+                key = phase[0] + "." + name
+                inner[key] = inner.get(key, 0.0) + 1e3 * (time.perf_counter() - t)
+                calls[key] = calls.get(key, 0) + 1
+                return out
+            return run
+        cnn.multiplexed_parallel_convolution = scoped("conv", cnn.multiplexed_parallel_convolution)
+        cnn.approx_relu = scoped("relu", cnn.approx_relu)
+        for name in ("rotate_many", "mul_plain_add", "rescale", "rotate_batch", "add", "bsgs", "batch", "mul_rescale", "mul", "mul_plain", "add_plain", "sub", "drop"):
+            setattr(ev, name, method(name, getattr(ev, name)))
+        net(x)
+        res["method_ms"] = {k: [round(v, 2), calls[k]] for k, v in sorted(inner.items(), key=lambda kv: -kv[1])}
     ctx.close()
+    return res
 
 
 if __name__ == "__main__":
-    main()
+    print(json.dumps(run(parse())), flush=True)
