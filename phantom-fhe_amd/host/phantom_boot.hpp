@@ -48,6 +48,7 @@ public:
     PhantomGaloisKey *galois_keys;
     double scale;
     hip_stream_wrapper stream;
+    bool auto_keys = false;  // generate a missing rotation key on first use (cnn_phantom.hpp: hundreds of steps)
 
 private:
     std::map<std::tuple<double, double, double, size_t>, PhantomPlaintext> consts_;
@@ -124,6 +125,10 @@ public:
         secret_key->add_galois_keys_from_elts(*context, elts, *galois_keys, stream);
     }
 
+    void ensure_keys(const std::vector<int> &steps) {
+        if (auto_keys) create_galois_keys_from_steps(steps, false);
+    }
+
     // ---- encode / encrypt / decrypt --------------------------------------------------------------------
     PhantomPlaintext encode(const cvec &values, double sc, size_t level, size_t slots) {
         PhantomPlaintext p;
@@ -144,6 +149,8 @@ public:
     PhantomCiphertext bsgs(const PhantomCiphertext &a, const std::vector<int> &baby_steps, const std::vector<int> &giant_steps,
                            const std::vector<const PhantomPlaintext *> &plains) {
         const int half = static_cast<int>(n() >> 1);
+        ensure_keys(baby_steps);
+        ensure_keys(giant_steps);
         std::vector<uint32_t> be, ge;
         std::vector<const uint64_t *const *> bk, gk;
         auto fill = [&](const std::vector<int> &steps, std::vector<uint32_t> &elts, std::vector<const uint64_t *const *> &keys) {
@@ -300,6 +307,7 @@ public:
     // all rotations of one ciphertext share its modup (pha_rotate_hoisted); steps that are multiples of N/2 copy
     std::vector<PhantomCiphertext> rotate_many(const PhantomCiphertext &a, const std::vector<int> &steps) {
         const int half = static_cast<int>(n() >> 1);
+        ensure_keys(steps);
         std::vector<PhantomCiphertext> out(steps.size());
         std::vector<uint32_t> elts;
         std::vector<const uint64_t *const *> evks;
@@ -321,6 +329,7 @@ public:
     PhantomCiphertext rotate(const PhantomCiphertext &a, int step) {
         PhantomCiphertext d = a.clone(s());
         if (step % static_cast<int>(n() >> 1) == 0) return d;
+        ensure_keys({step});
         const uint32_t e = elt(step);
         check(pha_apply_galois_inplace(h(), d.chain_index(), d.data(), e, galois_keys->get_relin_keys(e).public_keys_ptr(), s()));
         return d;
@@ -504,7 +513,18 @@ class ChebyshevEvaluator {
     CKKSEvaluator *ev_;
     std::vector<double> c_;
     int m_, l_;
+    bool optimal_ = false;  // depth ceil(log2(d+1)): a leaf c1 T1 + c2 T2 + c3 T3 is (c1 - c3) T1 + c2 T2 + (2 c3 T1) T2
     std::map<int, PhantomCiphertext> T_;
+    std::map<std::pair<int, size_t>, PhantomCiphertext> dropped_;
+    // T_j at `level` (dropping limbs copies the ciphertext: once per level)
+    const PhantomCiphertext &at(int j, size_t level) {
+        const PhantomCiphertext &t = T_.at(j);
+        if (t.chain_index() == level) return t;
+        auto key = std::make_pair(j, level);
+        auto it = dropped_.find(key);
+        if (it == dropped_.end()) it = dropped_.emplace(key, ev_->drop(t, level)).first;
+        return it->second;
+    }
 
     struct Val {
         enum Kind { NONE, CONST, CT } kind = NONE;
@@ -525,8 +545,9 @@ class ChebyshevEvaluator {
     }
     void powers(const PhantomCiphertext &w) {
         T_.clear();
+        dropped_.clear();
         T_.emplace(1, w.clone(ev_->stream.get_stream()));
-        for (int j = 2; j < (1 << l_); j++) {  // babies T_2 .. T_{2^l - 1}
+        for (int j = 2; j < (optimal_ ? 3 : (1 << l_)); j++) {  // babies T_2 .. T_{2^l - 1} (T_3 is never formed at optimal depth)
             int a = 1;
             while (2 * a <= j) a <<= 1;
             T_.emplace(j, j == a ? product(j / 2, j / 2) : product(a, j - a));
@@ -542,17 +563,32 @@ class ChebyshevEvaluator {
         const size_t lvl = level - 1;
         const double ql = ev_->q_last(lvl);
         PhantomCiphertext acc;
-        for (size_t j = 1; j < c.size(); j++) {
-            if (std::abs(c[j]) < 1e-300) continue;
-            PhantomCiphertext tmp;
-            const PhantomCiphertext &t = ev_->at_level(T_.at(static_cast<int>(j)), lvl, tmp);
-            ev_->mul_plain_add(acc, t, ev_->const_pt(c[j], scale * ql / t.scale(), lvl));
+        std::vector<double> cc = c;
+        if (optimal_ && cc.size() > 3 && std::abs(cc[3]) >= 1e-300) {
+            // (2 c3 T1) T2; T3 = 2 T1 T2 - T1 puts -c3 on T1
+            const PhantomCiphertext &t1 = at(1, lvl - 1), &t2 = at(2, lvl);
+            PhantomCiphertext a = ev_->rescale(ev_->mul_const(t1, 2.0 * cc[3], (scale * ql / t2.scale()) * ev_->q_last(lvl - 1) / t1.scale()));
+            const double kappa = (cc[1] - cc[3]) / (2.0 * cc[3]);
+            if (std::abs(cc[2]) < 1e-300 && std::abs(kappa) <= 16.0) {
+                // an odd leaf: (2 c3 T1)(T2 + kappa) is the whole of it, one merged product
+                out.kind = Val::CT;
+                out.ct = ev_->mul_rescale(a, ev_->add_const(t2, kappa));
+                if (std::abs(cc[0]) >= 1e-300) out.ct = ev_->add_const(out.ct, cc[0]);
+                return out;
+            }
+            acc = ev_->mul(a, t2);  // unrescaled at (lvl, scale * ql)
+            cc = {cc[0], cc[1] - cc[3], cc[2]};
+        }
+        for (size_t j = 1; j < cc.size(); j++) {
+            if (std::abs(cc[j]) < 1e-300) continue;
+            const PhantomCiphertext &t = at(static_cast<int>(j), lvl);
+            ev_->mul_plain_add(acc, t, ev_->const_pt(cc[j], scale * ql / t.scale(), lvl));
         }
         if (acc.data() == nullptr) {
-            if (std::abs(c[0]) >= 1e-300) out.kind = Val::CONST, out.c = c[0];
+            if (std::abs(cc[0]) >= 1e-300) out.kind = Val::CONST, out.c = cc[0];
             return out;
         }
-        if (std::abs(c[0]) >= 1e-300) acc = ev_->add_const(acc, c[0]);
+        if (std::abs(cc[0]) >= 1e-300) acc = ev_->add_const(acc, cc[0]);
         out.kind = Val::CT;
         out.ct = ev_->rescale(acc);
         return out;
@@ -574,8 +610,7 @@ class ChebyshevEvaluator {
             qc[j - hh] = 2.0 * c[j];
             r[2 * hh - j] -= c[j];
         }
-        PhantomCiphertext tmp;
-        const PhantomCiphertext &Th = ev_->at_level(T_.at(static_cast<int>(hh)), level - 1, tmp);
+        const PhantomCiphertext &Th = at(static_cast<int>(hh), level - 1);
         const double qscale = scale * ev_->q_last(level - 1) / Th.scale();
         Val qv = eval(std::move(qc), k - 1, level - 1, qscale);
         Val rv = eval(std::move(r), k - 1, level, scale);
@@ -598,12 +633,14 @@ class ChebyshevEvaluator {
 
 public:
     ChebyshevEvaluator() : ev_(nullptr), m_(1), l_(1) {}
-    ChebyshevEvaluator(CKKSEvaluator *ev, std::vector<double> coeffs, int baby_log = 2) : ev_(ev), c_(std::move(coeffs)) {
+    ChebyshevEvaluator(CKKSEvaluator *ev, std::vector<double> coeffs, int baby_log = 2, bool optimal_depth = false)
+        : ev_(ev), c_(std::move(coeffs)), optimal_(optimal_depth) {
         const double d = static_cast<double>(c_.size()) - 1.0;
-        m_ = std::max(1, static_cast<int>(std::ceil(std::log2(d + 1.0))));
+        m_ = std::max(optimal_ ? 2 : 1, static_cast<int>(std::ceil(std::log2(d + 1.0))));
         l_ = std::min(baby_log, m_);
+        if (optimal_ && l_ != 2) throw std::invalid_argument("the optimal-depth leaves need baby_log = 2");
     }
-    int depth() const { return m_ + 1; }
+    int depth() const { return optimal_ ? m_ : m_ + 1; }
     // Chebyshev interpolant of f at the degree + 1 Chebyshev points of the first kind
     static std::vector<double> interpolate(const std::function<double(double)> &f, int degree) {
         const int nn = degree + 1;
@@ -622,6 +659,7 @@ public:
         powers(w);
         Val v = eval(c_, m_, w.chain_index() + depth(), target_scale);
         T_.clear();
+        dropped_.clear();
         if (v.kind != Val::CT) throw std::logic_error("the polynomial is constant");
         return std::move(v.ct);
     }
@@ -638,6 +676,7 @@ public:
     CKKSEvaluator *ckks = nullptr;
     std::vector<long> slot_vec;
     int lt_levels = 3;        // groups per linear transform (the "_3" of the reference's API)
+    int s2c_lt_levels = 0;    // groups of SlotToCoeff when they differ (0: lt_levels)
     bool concurrent_evalmod = true;  // real and imaginary EvalMod on two (context, stream) pairs
     double evalmod_scale = 0;  // 0: the power of two nearest to the first EvalMod prime
 
@@ -649,12 +688,14 @@ private:
     double delta_ = 0, Kb_ = 0;
     bool prepared_ = false, generated_ = false;
 
-    int groups() const { return std::max(1, std::min<int>(lt_levels, static_cast<int>(logn))); }
+    int groups(bool s2c = false) const {
+        return std::max(1, std::min<int>(s2c && s2c_lt_levels > 0 ? s2c_lt_levels : lt_levels, static_cast<int>(logn)));
+    }
     size_t slots() const { return size_t(1) << logn; }
     void plan_levels() {
         evalmod_level_ = 1 + groups();
         s2c_level_ = evalmod_level_ + cheb_.depth() + scale_factor;
-        out_level_ = s2c_level_ + groups();
+        out_level_ = s2c_level_ + groups(true);
         if (out_level_ > ckks->bottom()) throw std::invalid_argument("the modulus chain is too short for bootstrapping");
         delta_ = evalmod_scale > 0 ? evalmod_scale : std::exp2(std::round(std::log2(ckks->q_last(evalmod_level_))));
     }
@@ -664,7 +705,7 @@ private:
         size_t lvl = 1;
         for (auto &g : special_fft_groups(S, groups(), true)) c2s_.emplace_back(ckks, std::move(g), S, lvl++);
         lvl = s2c_level_;
-        for (auto &g : special_fft_groups(S, groups(), false)) s2c_.emplace_back(ckks, std::move(g), S, lvl++);
+        for (auto &g : special_fft_groups(S, groups(true), false)) s2c_.emplace_back(ckks, std::move(g), S, lvl++);
     }
     PhantomCiphertext eval_mod(CKKSEvaluator &ev, ChebyshevEvaluator &cheb, const PhantomCiphertext &w) {
         PhantomCiphertext c = cheb(w, delta_);
@@ -731,7 +772,7 @@ private:
     // re-create the transforms with every diagonal multiplied by `cst`, then encode
     void rebuild(std::vector<DiagonalTransform> &ts, bool inverse, double cst, const std::function<double(size_t, size_t)> &scale_of) {
         const int S = static_cast<int>(slots());
-        std::vector<DiagMap> maps = special_fft_groups(S, groups(), inverse);
+        std::vector<DiagMap> maps = special_fft_groups(S, groups(!inverse), inverse);
         const size_t first = ts.front().level();
         ts.clear();
         for (size_t i = 0; i < maps.size(); i++) {

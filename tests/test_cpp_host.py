@@ -30,6 +30,28 @@ def test_bootstrap_header_mirrors_the_reference_api():
     assert "oracle" not in hdr
 
 
+def test_cnn_header_mirrors_the_reference_api():
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "phantom-fhe_amd", "host", "cnn_phantom.hpp")).read()
+    for name in ("class TensorCipher", "multiplexed_parallel_convolution_phantom", "multiplexed_parallel_batch_norm_phantom",
+                 "ReLU_phantom", "cnn_add_phantom", "multiplexed_parallel_downsampling_phantom", "averagepooling_phantom_scale",
+                 "matrix_multiplication_phantom", "import_parameters_cifar10"):
+        assert name in hdr
+    assert "oracle" not in hdr
+
+
+@pytest.mark.gpu
+def test_cpp_resnet_with_bootstrapping(gpu):
+    """The flow of the reference's examples/cnn.cu on the C++ host layer (cnn_phantom.hpp): three residual blocks on
+    8 x 8 images at N = 2^13, six bootstrappings, logits against the same network on plain numbers."""
+    exe = os.path.join(os.path.dirname(__file__), "cpp", "cnn_test")
+    assert os.path.exists(exe), "tests/cpp/cnn_test not built (run __graft_entry__.build())"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["resnet8_2^13"]
+    assert res["bootstrappings"] == 6 and res["relu_levels"] == 14 and res["relu_alpha"] > 13.0
+    assert res["max_logit_error_vs_plain_same_relu"] < 1e-3 and res["argmax"] == res["argmax_plain"]
+
+
 @pytest.mark.gpu
 def test_cpp_bootstrapper(gpu):
     """The flow of the reference's examples/bootstrapping.cu on the C++ host layer: full slots (2048 of N = 2^12)

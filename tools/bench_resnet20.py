@@ -59,6 +59,7 @@ def parse(argv=None):
     ap.add_argument("--evalmod-bits", type=int, default=56)
     ap.add_argument("--image-seed", type=int, default=0)
     ap.add_argument("--graph", action="store_true", help="also capture the inference in one HIP graph and time its replay")
+    ap.add_argument("--streams", type=int, default=1, help="2: a second, independent inference on a sibling (context, stream) pair, both as HIP graphs (throughput)")
     ap.add_argument("--phases", action="store_true", help="synchronise after every block and print where the time goes")
     return ap.parse_args(argv)
 
@@ -123,6 +124,38 @@ def run(args):
             gt.append(time.perf_counter() - t0)
         res["graph_replay_ms"] = 1e3 * min(gt)
         res["graph_logit_diff"] = float(np.abs(net.decrypt_logits(gout) - logits).max())
+    if args.streams == 2:
+        # two images in flight: the second on a sibling evaluator (same keys, own library context and stream) with its
+        # own bootstrappers and constants; both inferences are HIP graphs, replayed side by side
+        ev2 = ev.sibling()
+        ev2.auto_keys = True
+        d, e, g, g2 = args.delta_bits, args.evalmod_bits, args.groups, args.s2c_groups or args.groups
+        with torch.cuda.stream(ev2.stream):
+            boot2 = {s: Bootstrapper(ev2, K=25, r=4, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d, transform="fft", c2s_groups=g, s2c_groups=g2, slots=s)
+                     for s in boot}
+            net2 = cnn.ResNetCifar10(ev2, params, layer_num=args.layers, B=40.0, relu=relu, bootstrappers=boot2)
+            image2 = smooth_image(args.image_seed + 1)
+            x2 = net2.encrypt_image(image2, 2.0 ** args.delta_bits, level)
+            logits2 = net2.decrypt_logits(net2(x2))
+            run2 = net2.capture(x2)
+        run1 = net.capture(x)
+        torch.cuda.synchronize()
+        pair = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            o1 = run1(x)
+            with torch.cuda.stream(ev2.stream):
+                o2 = run2(x2)
+            torch.cuda.synchronize()
+            pair.append(time.perf_counter() - t0)
+        want2 = cnn_ref.resnet_cifar10(params, image2, net.end_num, relu=lambda v: B * relu(v / B))
+        with torch.cuda.stream(ev2.stream):
+            got2 = net2.decrypt_logits(o2)
+        res["two_streams_ms_for_two_images"] = 1e3 * min(pair)
+        res["images_per_s_two_streams"] = 2.0 / min(pair)
+        res["images_per_s_one_stream"] = 1.0 / min(times)
+        res["two_streams_logit_errors"] = [float(np.abs(net.decrypt_logits(o1) - want).max()), float(np.abs(got2 - want2).max())]
     if args.phases:
         res["block_errors"] = block_err
         spent = {}
