@@ -301,7 +301,7 @@ class Bootstrapper:
     parts go through EvalMod as two ciphertexts."""
 
     def __init__(self, ev, K=12, r=3, degree=31, delta=2.0 ** 40, baby_log=2, packed=None,
-                 transform="dense", c2s_groups=3, s2c_groups=3, msg_scale=None, slots=None):
+                 transform="dense", c2s_groups=3, s2c_groups=3, msg_scale=None, slots=None, slim=False):
         """delta: the scale EvalMod works at (its primes should be close to it); msg_scale: the scale of
         the ciphertexts to refresh (default delta).  A delta well above msg_scale (say 2^58 against 2^46)
         lowers the EvalMod noise floor, which full slots see amplified by sqrt(s) * q0 / (2 pi msg_scale)."""
@@ -310,7 +310,11 @@ class Bootstrapper:
         s, n = (ev.s if slots is None else slots), ev.n      # slots: several packings on one evaluator (cnn.py)
         self.s = s
         self.transform = transform
+        self.slim = slim
+        self.pre_levels = 0
+        self.delta_out = delta               # scale of the Chebyshev polynomial's result (the slim order tunes it)
         assert transform in ("dense", "fft")
+        assert not slim or transform == "fft", "the slim order is built on the FFT-factored transforms"
         # packing doubles the dimension of the dense linear transforms: it pays while they are small
         self.packed = (4 * s <= n and s <= 64 and transform == "dense") if packed is None else packed
         assert not (self.packed and transform == "fft"), "the FFT-factored transforms run unpacked"
@@ -323,7 +327,9 @@ class Bootstrapper:
         self.cheb = ChebyshevEvaluator(ev, np.polynomial.chebyshev.chebinterpolate(f, degree), baby_log)
         q0 = ev.q[0]
         norm = 1.0 / (self.g * self.Kb * 2.0)
-        if transform == "fft":
+        if slim:
+            self._init_slim(norm, c2s_groups, s2c_groups)
+        elif transform == "fft":
             self._init_fft(norm, c2s_groups, s2c_groups)
         else:
             self._init_dense(norm)
@@ -339,7 +345,7 @@ class Bootstrapper:
     def _evalmod_out(self, level):
         """(scale, level) of the EvalMod output: delta after the polynomial, squared and rescaled by every
         double angle"""
-        sv, lvl = self.delta, level + self.cheb.depth
+        sv, lvl = self.delta_out, level + self.cheb.depth
         for _ in range(self.r):
             sv, lvl = sv * sv / self.ev.q_last(lvl), lvl + 1
         return sv, lvl
@@ -404,6 +410,42 @@ class Bootstrapper:
             lvl += 1
         self.out_level = lvl
 
+    def _init_slim(self, norm, c2s_groups, s2c_groups):
+        """SlotToCoeff FIRST, on the last levels of the chain (a few limbs: nearly free), then modulus raise,
+        CoeffToSlot and EvalMod, whose output already holds the message in the slots (Chen, Chillotti, Song 2019).
+        Against the usual order: SlotToCoeff at 2-3 limbs instead of ~18, and the EvalMod error reaches the slots
+        directly instead of through a transform that spreads it over sqrt(s) coefficients.  The factor
+        q0 / (2 pi msg_scale) that the usual order folds into the SlotToCoeff diagonals is a re-declaration of the
+        scale here, and the scale delta_out on which the Chebyshev polynomial lands (any exact target costs nothing:
+        its constants are encoded accordingly) is CHOSEN so that this re-declared scale equals the input scale:
+        delta_out^(2^r) / prod q_i^(2^(r-i)) = q0 / (2 pi) over the primes q_i of the r double-angle levels.  The
+        powers of the polynomial's argument stay at the nominal scale delta (close to the EvalMod primes)."""
+        ev, S, r = self.ev, self.S, self.r
+        q0 = ev.q[0]
+        inv = special_fft_groups(S, min(c2s_groups, max(1, S.bit_length() - 1)), True)
+        fwd = special_fft_groups(S, min(s2c_groups, max(1, S.bit_length() - 1)), False)
+        self.evalmod_level = 1 + len(inv)
+        lvl0 = self.evalmod_level + self.cheb.depth
+        log_delta = math.log2(q0 / (2.0 * np.pi))
+        for i in range(r):
+            log_delta += (1 << (r - 1 - i)) * math.log2(ev.q_last(lvl0 + i))
+        self.delta_out = 2.0 ** (log_delta / (1 << r))
+        delta = self.delta
+        self.c2s, lvl = [], 1
+        cst = norm ** (1.0 / len(inv))
+        for i, g in enumerate(inv):
+            last = i + 1 == len(inv)
+            scale = ev.q_last(lvl) * (delta / q0 if last else 1.0)
+            self.c2s.append(DiagonalTransform(ev, {d: v * cst for d, v in g.items()}, S, lvl, scale))
+            lvl += 1
+        sv, self.out_level = self._evalmod_out(self.evalmod_level)
+        assert abs(sv * 2.0 * np.pi / q0 - 1.0) < 1e-9
+        self.sv = sv
+        # the forward transform on the last len(fwd) levels, scale-preserving
+        self.pre_levels = len(fwd)
+        self.s2c_level = ev.bottom - len(fwd)
+        self.s2c = [DiagonalTransform(ev, g, S, self.s2c_level + i, ev.q_last(self.s2c_level + i)) for i, g in enumerate(fwd)]
+
     def levels_needed(self):
         return self.out_level
 
@@ -411,7 +453,7 @@ class Bootstrapper:
         """w in [-1, 1] real slots, w = (m/q0 + I)/Kb  ->  sin(2 pi (m/q0 + I)) ~ 2 pi m / q0"""
         ev = self.ev if ev is None else ev
         cheb = self.cheb if ev is self.ev else ChebyshevEvaluator(ev, self.cheb.c, self.cheb.l)
-        c = cheb(w, self.delta)
+        c = cheb(w, self.delta_out)
         for _ in range(self.r):
             c = ev.square_double_minus_one(c)
         return c
@@ -419,8 +461,14 @@ class Bootstrapper:
     def bootstrap(self, ct):
         ev = self.ev
         in_scale = ct.scale
-        assert abs(in_scale / self.msg_scale - 1.0) < 0.01, "the bootstrapper was set up for ciphertexts of scale msg_scale"
         q0 = ev.q[0]
+        if self.slim:
+            assert ct.level <= self.s2c_level, "the slim order spends its SlotToCoeff levels before the modulus raise"
+            ct = ev.drop(ct, self.s2c_level)
+            for lt in self.s2c:
+                ct = lt.apply(ct)
+        else:
+            assert abs(in_scale / self.msg_scale - 1.0) < 0.01, "the bootstrapper was set up for ciphertexts of scale msg_scale"
         t = ev.mod_raise(ev.drop(ct, ev.bottom))
         t.scale = float(q0)                                   # src/boot/Bootstrapper.cu:2867-2868
         k = self.S
@@ -439,6 +487,9 @@ class Bootstrapper:
             # two independent EvalMods: side by side where the evaluator can (two streams on the GPU)
             a, b = ev.run_pair(lambda e: self.eval_mod(re, e), lambda e: self.eval_mod(im, e))
             v = ev.add(a, ev.mul_i(b))                            # 2 pi (m_k + i m_{k+s}) / q0
+        if self.slim:
+            v.scale = v.scale * 2.0 * np.pi * in_scale / q0       # = in_scale by the choice of delta
+            return v
         out = v
         for lt in self.s2c:
             out = lt.apply(out)                           # slots: message * in_scale / delta

@@ -518,8 +518,14 @@ class ResNetCifar10:
         self.trace = None
 
     def levels_after_bootstrap(self):
-        """levels one block needs between two bootstrappings: ReLU, then a convolution (2)"""
-        return self.relu.depth + 2
+        """levels one block needs between two bootstrappings: ReLU, then a convolution (2), then whatever the
+        bootstrapper spends before its modulus raise (the slim order's SlotToCoeff)"""
+        pre = max((b.pre_levels for b in self.boot.values()), default=0) if self.boot else 0
+        return self.relu.depth + 2 + pre
+
+    def input_level(self):
+        """level to encrypt the image at: the first convolution comes before the first ReLU"""
+        return self.ev.bottom - self.levels_after_bootstrap() - 2
 
     def encrypt_image(self, image, scale, level):
         """image [c][h][w] in the network's units; the ciphertext holds image / B (examples/cnn.cu:263-278)"""

@@ -100,6 +100,52 @@ def test_fft_bootstrap_on_the_simulator(orc, pha, log_n, s, groups):
     assert np.abs(ev.decrypt_decode(out) - msg).max() < 3e-5
 
 
+@pytest.mark.parametrize("log_n,s,groups", [(12, 256, 3), (12, 32, 2), (8, 128, 3), (9, 256, 4)])
+def test_slim_bootstrap_on_the_simulator(orc, pha, log_n, s, groups):
+    """SlotToCoeff first (on the last levels), then modulus raise, CoeffToSlot, EvalMod: the output scale is the
+    input scale by the choice of the EvalMod scale, whatever the input scale is"""
+    from phantom_fhe_amd.bootstrap import Bootstrapper
+    from phantom_fhe_amd.ckks import SimEvaluator
+    n = 1 << log_n
+    q = [int(v) for v in _fft_chain(orc, n, groups)]
+    ev = SimEvaluator(log_n, q, s, hamming_weight=32, seed=s)
+    bs = Bootstrapper(ev, K=12, r=3, degree=31, transform="fft", c2s_groups=groups, s2c_groups=groups, slim=True)
+    assert bs.levels_needed() == groups + 10 and bs.pre_levels == min(groups, s.bit_length() - 1)
+    rng = np.random.default_rng(1)
+    msg = rng.uniform(-1, 1, s) + 1j * rng.uniform(-1, 1, s)
+    for scale in (2.0 ** 40, 1.37 * 2.0 ** 39):
+        out = bs.bootstrap(ev.encrypt(ev.encode(msg, scale, ev.bottom - bs.pre_levels)))
+        assert np.abs(ev.last_I).max() >= 3
+        assert out.level == bs.levels_needed() and abs(out.scale / scale - 1) < 1e-9
+        assert np.abs(ev.decrypt_decode(out) - msg).max() < 3e-5
+    with pytest.raises(AssertionError):
+        bs.bootstrap(ev.encrypt(ev.encode(msg, 2.0 ** 40, ev.bottom)))        # no level left for SlotToCoeff
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("s,groups,d,e", [(2048, 3, 50, 50), (2048, 4, 40, 58), (128, 2, 40, 40)])
+def test_slim_bootstrap_on_the_gpu(gpu, pha, orc, s, groups, d, e):
+    """the slim order on real ciphertexts: the EvalMod error reaches the slots without the sqrt(s) of a
+    SlotToCoeff behind it (compare the tolerances of test_fft_bootstrap_on_the_gpu)"""
+    from phantom_fhe_amd.bootstrap import Bootstrapper
+    from phantom_fhe_amd.ckks import GpuEvaluator
+    mods = _fft_chain(orc, N, groups, extra=[60], d=d, e=e)
+    ctx = pha.PhantomContext(LOG_N, mods, 1)
+    sk = ctx.gen_secretkey(23, hamming_weight=32)
+    ev = GpuEvaluator(pha, ctx, sk, s)
+    bs = Bootstrapper(ev, K=12, r=3, degree=31, delta=2.0 ** e, transform="fft", c2s_groups=groups, s2c_groups=groups, slim=True)
+    rng = np.random.default_rng(3)
+    msg = rng.uniform(-1, 1, s) + 1j * rng.uniform(-1, 1, s)
+    ct = ev.encrypt(ev.encode(msg, 2.0 ** d, ev.bottom - bs.pre_levels))
+    out = bs.bootstrap(ct)
+    assert out.level == groups + 10 and abs(out.scale / ct.scale - 1) < 1e-9
+    err = np.abs(ev.decrypt_decode(out) - msg).max()
+    assert err < (1e-3 if e == 40 else 2e-5), err
+    sq = ev.rescale(ev.mul(out, out))
+    assert np.abs(ev.decrypt_decode(sq) - msg * msg).max() < (2e-3 if e == 40 else 1e-4)
+    ctx.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("s,groups,d,e", [(2048, 3, 50, 50), (2048, 4, 40, 58), (128, 2, 40, 40)])
 def test_fft_bootstrap_on_the_gpu(gpu, pha, orc, s, groups, d, e):

@@ -180,7 +180,8 @@ def test_parameter_files(tmp_path):
 
 
 @pytest.mark.gpu
-def test_resnet8_with_bootstrapping_on_the_gpu():
+@pytest.mark.parametrize("slim", [True, False])
+def test_resnet8_with_bootstrapping_on_the_gpu(slim):
     """N = 2^13, 8 x 8 images: three residual blocks, six bootstrappings (1024, 512 and 256 sparse slots), every
     ciphertext operation through the C ABI; logits against the plain network with the same ReLU polynomial."""
     import torch
@@ -196,14 +197,14 @@ def test_resnet8_with_bootstrapping_on_the_gpu():
     sk = ctx.gen_secretkey(21, hamming_weight=32)
     ev = GpuEvaluator(pha, ctx, sk, n // 2)
     ev.auto_keys = True
-    boot = {s: Bootstrapper(ev, K=12, r=3, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d, transform="fft", c2s_groups=g, s2c_groups=g, slots=s)
-            for s in (n // 8, n // 16, n // 32)}
+    boot = {s: Bootstrapper(ev, K=12, r=3, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d, transform="fft", c2s_groups=g, s2c_groups=g, slots=s,
+                            slim=slim) for s in (n // 8, n // 16, n // 32)}
     params = cnn_ref.synthetic_parameters(0, seed=3)
     net = cnn.ResNetCifar10(ev, params, layer_num=8, B=16.0, relu=relu, image_shape=(3, 8, 8), bootstrappers=boot)
     image = np.random.default_rng(3).normal(0.0, 1.0, (3, 8, 8))
-    x = net.encrypt_image(image, 2.0 ** d, ev.bottom - net.levels_after_bootstrap() - 2)
+    x = net.encrypt_image(image, 2.0 ** d, net.input_level())
     out = net(x)
-    assert out.ct.level == ev.bottom - net.levels_after_bootstrap() + relu.depth + 2      # average pooling and the linear layer: two levels
+    assert out.ct.level == next(iter(boot.values())).out_level + relu.depth + 2      # average pooling and the linear layer: two levels
     logits = net.decrypt_logits(out)
     B = net.B
     want = cnn_ref.resnet_cifar10(params, image, 0, relu=lambda v: B * relu(v / B))

@@ -43,7 +43,7 @@ def build(args):
     ev.auto_keys = True
     boot = {}
     for s in (n // 4, n // 8, n // 16):
-        boot[s] = Bootstrapper(ev, K=25, r=4, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d, transform="fft", c2s_groups=g, s2c_groups=g2, slots=s)
+        boot[s] = Bootstrapper(ev, K=25, r=4, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d, transform="fft", c2s_groups=g, s2c_groups=g2, slots=s, slim=not args.no_slim)
     return ctx, ev, boot, relu, mods
 
 
@@ -58,6 +58,7 @@ def parse(argv=None):
     ap.add_argument("--delta-bits", type=int, default=42)
     ap.add_argument("--evalmod-bits", type=int, default=56)
     ap.add_argument("--image-seed", type=int, default=0)
+    ap.add_argument("--no-slim", action="store_true", help="SlotToCoeff after EvalMod (the usual order) instead of before the modulus raise")
     ap.add_argument("--graph", action="store_true", help="also capture the inference in one HIP graph and time its replay")
     ap.add_argument("--streams", type=int, default=1, help="2: a second, independent inference on a sibling (context, stream) pair, both as HIP graphs (throughput)")
     ap.add_argument("--phases", action="store_true", help="synchronise after every block and print where the time goes")
@@ -73,7 +74,7 @@ def run(args):
         params = cnn_ref.synthetic_parameters({8: 0, 14: 1, 32: 4}[args.layers], seed=1)
     net = cnn.ResNetCifar10(ev, params, layer_num=args.layers, B=40.0, relu=relu, bootstrappers=boot)
     image = smooth_image(args.image_seed)
-    level = ev.bottom - net.levels_after_bootstrap() - 2     # the first convolution comes before the first ReLU
+    level = net.input_level()
     x = net.encrypt_image(image, 2.0 ** args.delta_bits, level)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
@@ -131,7 +132,7 @@ def run(args):
         ev2.auto_keys = True
         d, e, g, g2 = args.delta_bits, args.evalmod_bits, args.groups, args.s2c_groups or args.groups
         with torch.cuda.stream(ev2.stream):
-            boot2 = {s: Bootstrapper(ev2, K=25, r=4, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d, transform="fft", c2s_groups=g, s2c_groups=g2, slots=s)
+            boot2 = {s: Bootstrapper(ev2, K=25, r=4, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d, transform="fft", c2s_groups=g, s2c_groups=g2, slots=s, slim=not args.no_slim)
                      for s in boot}
             net2 = cnn.ResNetCifar10(ev2, params, layer_num=args.layers, B=40.0, relu=relu, bootstrappers=boot2)
             image2 = smooth_image(args.image_seed + 1)
