@@ -678,7 +678,14 @@ public:
         logn = static_cast<int>(ev->context->log_n()) - 1;
         init_p = static_cast<int>(cnn_detail::floor_pow2(static_cast<double>(1L << logn) / (h * w * c)));
     }
-    int levels_after_bootstrap() const { return relu.depth + 2; }
+    // levels one block needs between two bootstrappings: ReLU, a convolution (2), and what the bootstrapper spends before
+    // its modulus raise (the slim order's SlotToCoeff)
+    int levels_after_bootstrap() const {
+        size_t pre = 0;
+        for (const auto &b : bootstrappers) pre = std::max(pre, b.second->pre_levels());
+        return relu.depth + 2 + static_cast<int>(pre);
+    }
+    size_t input_level() const { return ev->bottom() - levels_after_bootstrap() - 2; }  // the first convolution comes before the first ReLU
 
     // image [c][h][w] in the network's units; the ciphertext holds image / B (examples/cnn.cu:263-278)
     TensorCipher encrypt_image(const std::vector<double> &image, double scale, size_t level) {

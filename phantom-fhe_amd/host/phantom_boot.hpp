@@ -677,6 +677,11 @@ public:
     std::vector<long> slot_vec;
     int lt_levels = 3;        // groups per linear transform (the "_3" of the reference's API)
     int s2c_lt_levels = 0;    // groups of SlotToCoeff when they differ (0: lt_levels)
+    // slim order (Chen, Chillotti, Song 2019): SlotToCoeff FIRST, on the last levels of the chain (a few limbs), then
+    // modulus raise, CoeffToSlot, EvalMod, whose result already holds the message in the slots.  The factor
+    // q0 / (2 pi scale) that the usual order folds into the SlotToCoeff diagonals is a re-declaration of the scale, and
+    // the scale on which the Chebyshev polynomial lands is chosen so that the output scale equals the input scale.
+    bool slim = false;
     bool concurrent_evalmod = true;  // real and imaginary EvalMod on two (context, stream) pairs
     double evalmod_scale = 0;  // 0: the power of two nearest to the first EvalMod prime
 
@@ -685,7 +690,7 @@ private:
     std::vector<double> cheb_coeffs_;
     std::vector<DiagonalTransform> c2s_, s2c_;
     size_t evalmod_level_ = 0, s2c_level_ = 0, out_level_ = 0;
-    double delta_ = 0, Kb_ = 0;
+    double delta_ = 0, delta_out_ = 0, Kb_ = 0;
     bool prepared_ = false, generated_ = false;
 
     int groups(bool s2c = false) const {
@@ -694,11 +699,27 @@ private:
     size_t slots() const { return size_t(1) << logn; }
     void plan_levels() {
         evalmod_level_ = 1 + groups();
-        s2c_level_ = evalmod_level_ + cheb_.depth() + scale_factor;
-        out_level_ = s2c_level_ + groups(true);
-        if (out_level_ > ckks->bottom()) throw std::invalid_argument("the modulus chain is too short for bootstrapping");
+        const size_t after_evalmod = evalmod_level_ + cheb_.depth() + scale_factor;
+        if (slim) {
+            out_level_ = after_evalmod;
+            if (out_level_ + groups(true) > ckks->bottom()) throw std::invalid_argument("the modulus chain is too short for bootstrapping");
+            s2c_level_ = ckks->bottom() - groups(true);
+        } else {
+            s2c_level_ = after_evalmod;
+            out_level_ = s2c_level_ + groups(true);
+            if (out_level_ > ckks->bottom()) throw std::invalid_argument("the modulus chain is too short for bootstrapping");
+        }
         delta_ = evalmod_scale > 0 ? evalmod_scale : std::exp2(std::round(std::log2(ckks->q_last(evalmod_level_))));
+        delta_out_ = delta_;
+        if (slim) {  // delta_out^(2^r) / prod q_i^(2^(r-i)) = q0 / (2 pi) over the primes of the r double-angle levels
+            const double kPi = 3.14159265358979323846;
+            double lg = std::log2(ckks->q(0) / (2.0 * kPi));
+            const size_t lvl0 = evalmod_level_ + cheb_.depth();
+            for (long i = 0; i < scale_factor; i++) lg += std::exp2(static_cast<double>(scale_factor - 1 - i)) * std::log2(ckks->q_last(lvl0 + i));
+            delta_out_ = std::exp2(lg / std::exp2(static_cast<double>(scale_factor)));
+        }
     }
+    size_t pre_levels_() const { return slim ? static_cast<size_t>(groups(true)) : 0; }
     void build_transforms() {
         if (!c2s_.empty()) return;
         const int S = static_cast<int>(slots());
@@ -708,7 +729,7 @@ private:
         for (auto &g : special_fft_groups(S, groups(true), false)) s2c_.emplace_back(ckks, std::move(g), S, lvl++);
     }
     PhantomCiphertext eval_mod(CKKSEvaluator &ev, ChebyshevEvaluator &cheb, const PhantomCiphertext &w) {
-        PhantomCiphertext c = cheb(w, delta_);
+        PhantomCiphertext c = cheb(w, delta_out_);
         for (long i = 0; i < scale_factor; i++) c = ev.square_double_minus_one(c);
         return c;
     }
@@ -723,6 +744,7 @@ public:
     }
     void set_final_scale(double _final_scale) { final_scale = _final_scale; }
     size_t levels_needed() const { return out_level_; }
+    size_t pre_levels() const { return pre_levels_(); }  // levels spent before the modulus raise (slim order)
 
     // the approximate polynomial: Chebyshev interpolant of cos(2 pi (Kb w - 1/4) / 2^r) on [-1, 1], Kb = K + 1/2
     void prepare_mod_polynomial() {
@@ -760,11 +782,15 @@ public:
         const double c2s_cst = std::pow(norm, 1.0 / n_c2s);
         rebuild(c2s_, true, c2s_cst, [&](size_t i, size_t lvl) { return ckks->q_last(lvl) * (i + 1 == n_c2s ? delta_ / q0 : 1.0); });
         // EvalMod output scale: delta after the polynomial, squared and rescaled by every double angle
-        double sv = delta_;
+        double sv = delta_out_;
         size_t lvl = evalmod_level_ + cheb_.depth();
         for (long i = 0; i < scale_factor; i++, lvl++) sv = sv * sv / ckks->q_last(lvl);
-        const double s2c_cst = std::pow((q0 / final_scale) / (2.0 * kPi), 1.0 / n_s2c);
-        rebuild(s2c_, false, s2c_cst, [&](size_t i, size_t l2) { return ckks->q_last(l2) * (i == 0 ? final_scale / sv : 1.0); });
+        if (slim) {  // the forward transform as it is, scale-preserving
+            rebuild(s2c_, false, 1.0, [&](size_t, size_t l2) { return ckks->q_last(l2); });
+        } else {
+            const double s2c_cst = std::pow((q0 / final_scale) / (2.0 * kPi), 1.0 / n_s2c);
+            rebuild(s2c_, false, s2c_cst, [&](size_t i, size_t l2) { return ckks->q_last(l2) * (i == 0 ? final_scale / sv : 1.0); });
+        }
         generated_ = true;
     }
 
@@ -791,10 +817,17 @@ public:
     // sparse (n < Nh: SubSum first) and full (n == Nh) packings take the same path
     void bootstrap_3(PhantomCiphertext &rtncipher, PhantomCiphertext &cipher) {
         if (!generated_) throw std::logic_error("generate_LT_coefficient_3() has not been called");
-        if (std::abs(cipher.scale() / final_scale - 1.0) > 0.01) throw std::invalid_argument("the bootstrapper was set up for ciphertexts of scale final_scale");
         const double in_scale = cipher.scale(), q0 = ckks->q(0);
-        PhantomCiphertext tmp;
-        PhantomCiphertext t = ckks->mod_raise(ckks->at_level(cipher, ckks->bottom(), tmp));
+        PhantomCiphertext tmp, pre;
+        const PhantomCiphertext *src = &cipher;
+        if (slim) {
+            if (cipher.chain_index() > s2c_level_) throw std::invalid_argument("the slim order spends its SlotToCoeff levels before the modulus raise");
+            pre = ckks->drop(cipher, s2c_level_);
+            for (auto &lt : s2c_) pre = lt.apply(pre);
+            src = &pre;
+        } else if (std::abs(cipher.scale() / final_scale - 1.0) > 0.01)
+            throw std::invalid_argument("the bootstrapper was set up for ciphertexts of scale final_scale");
+        PhantomCiphertext t = ckks->mod_raise(ckks->at_level(*src, ckks->bottom(), tmp));
         t.set_scale(q0);  // src/boot/Bootstrapper.cu:2867-2868
         for (long k = n; k < Nh; k <<= 1) {  // SubSum onto the n-slot subring (:2870-2876)
             PhantomCiphertext r = ckks->rotate(t, static_cast<int>(k));
@@ -817,6 +850,11 @@ public:
             vi = ckks->mul_i(eval_mod(*ckks, cheb_, im));
         }
         ckks->add_inplace(v, vi);
+        if (slim) {
+            v.set_scale(v.scale() * 2.0 * 3.14159265358979323846 * in_scale / q0);  // = in_scale by the choice of delta_out
+            rtncipher = std::move(v);
+            return;
+        }
         for (auto &lt : s2c_) v = lt.apply(v);
         v.set_scale(v.scale() * in_scale / final_scale);  // src/boot/Bootstrapper.cu:2933 (a ratio of ~1)
         rtncipher = std::move(v);

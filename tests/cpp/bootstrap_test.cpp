@@ -11,7 +11,7 @@ using namespace phantom;
 
 static int run_case(const char *name, long logN, long logn, int logp, int logq0, int log_evalmod, int log_c2s, int remaining_level,
                     size_t special, int reps, long boundary_K = 12, long scale_factor = 3, size_t hamming_weight = 32,
-                    int lt_levels = 3) {
+                    int lt_levels = 3, bool slim = false) {
     const long deg = 31, inverse_deg = 1, loge = 10;
     const int lt = std::min<long>(lt_levels, logn), boot_level = lt + (5 + 1) + static_cast<int>(scale_factor) + lt;
     std::vector<int> coeff_bit_vec;
@@ -42,6 +42,8 @@ static int run_case(const char *name, long logN, long logn, int logp, int logq0,
 
     Bootstrapper bootstrapper(loge, logn, logN - 1, total_level, scale, boundary_K, deg, scale_factor, inverse_deg, &ckks_evaluator);
     bootstrapper.lt_levels = lt;
+    bootstrapper.slim = slim;
+    bootstrapper.evalmod_scale = std::pow(2.0, log_evalmod);
     bootstrapper.prepare_mod_polynomial();
     std::vector<int> gal_steps_vector;
     gal_steps_vector.push_back(0);
@@ -57,7 +59,7 @@ static int run_case(const char *name, long logN, long logn, int logp, int logq0,
     for (auto &v : msg) v = {dist(rnd), dist(rnd)};
     // encode at the top, walk down to the last level like the example does
     PhantomCiphertext cipher = ckks_evaluator.encrypt(ckks_evaluator.encode(msg, scale, 1, sparse_slots));
-    for (int i = 0; i < total_level; i++) mod_switch_to_next_inplace(context, cipher, ckks_evaluator.stream);
+    for (int i = 0; i < total_level - static_cast<int>(bootstrapper.pre_levels()); i++) mod_switch_to_next_inplace(context, cipher, ckks_evaluator.stream);
     cvec before = ckks_evaluator.decrypt_decode(cipher, sparse_slots);
 
     PhantomCiphertext rtn;
@@ -97,10 +99,13 @@ int main(int argc, char **argv) {
             // N = 2^16, full slots, the shape of tools/bench_bootstrap.py --slots 32768 --transform fft
             // (bench 4: four levels per transform, 13 remaining levels)
             if (argc > 2 && std::string(argv[2]) == "4") return run_case("bench_full_2^16_lt4", 16, 15, 46, 56, 58, 60, 13, 4, 3, 25, 4, 192, 4);
+            if (argc > 2 && std::string(argv[2]) == "slim") return run_case("bench_full_2^16_lt4_slim", 16, 15, 46, 56, 58, 60, 9, 4, 3, 25, 4, 192, 4, true);
             return run_case("bench_full_2^16", 16, 15, 46, 56, 58, 60, 15, 4, 3, 25, 4, 192);
         }
         run_case("full_slots", 12, 11, 50, 60, 50, 60, 2, 1, 1);
         run_case("sparse_128", 12, 7, 40, 50, 40, 58, 2, 1, 1);
+        run_case("full_slots_slim", 12, 11, 50, 60, 50, 60, 2, 1, 1, 12, 3, 32, 3, true);
+        run_case("sparse_128_slim", 12, 7, 40, 50, 40, 58, 2, 1, 1, 12, 3, 32, 3, true);
         // a wrong scale is refused like the reference's argument checks
         return 0;
     } catch (const std::exception &e) {

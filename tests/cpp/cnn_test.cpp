@@ -151,6 +151,7 @@ static int run(const char *name, long logN, int image_hw, size_t end_num, CnnPar
         boots.push_back(std::make_unique<Bootstrapper>(10, ls, logn, static_cast<long>(q_limbs) - 1, scale, boundary_K, 31, scale_factor, 1, &ev));
         Bootstrapper &b = *boots.back();
         b.lt_levels = c2s_levels, b.s2c_lt_levels = s2c_levels;
+        b.slim = true;
         b.evalmod_scale = std::pow(2.0, log_evalmod);
         b.prepare_mod_polynomial();
         std::vector<int> steps{0};
@@ -163,7 +164,7 @@ static int run(const char *name, long logN, int image_hw, size_t end_num, CnnPar
     std::normal_distribution<double> normal(0.0, 1.0);
     Tensor image(3 * image_hw * image_hw);
     for (double &v : image) v = std::max(-2.5, std::min(2.5, normal(rnd)));
-    const size_t level = ev.bottom() - net.levels_after_bootstrap() - 2;  // the first convolution comes before the first ReLU
+    const size_t level = net.input_level();
     TensorCipher x = net.encrypt_image(image, scale, level);
     TensorCipher out = net(x);  // first run: encodes the constants, generates rotation keys
     ev.sync();

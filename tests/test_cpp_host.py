@@ -69,6 +69,11 @@ def test_cpp_bootstrapper(gpu):
     assert full["input_err"] < 1e-9 and full["max_err"] < 2e-5 and full["square_err"] < 4e-5      # delta = 2^50
     assert sparse["slots"] == 128 and sparse["return_limbs"] == 3
     assert sparse["max_err"] < 1e-3 and sparse["mean_err"] < 2e-4 and sparse["square_err"] < 2e-3  # delta = 2^40
+    # slim order: SlotToCoeff first (3 levels at the end of the chain), the result comes back 3 levels earlier
+    fs, ss = res["full_slots_slim"], res["sparse_128_slim"]
+    assert fs["return_level"] == fs["levels_needed"] == 13 and fs["return_limbs"] == 6
+    assert fs["max_err"] < 3e-5 and fs["square_err"] < 1e-4            # floor: the sine's cubic term at |z| ~ 1.4
+    assert ss["return_level"] == 13 and ss["max_err"] < 1e-4 and ss["mean_err"] < 2e-5
 
 
 @pytest.mark.gpu

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--delta-bits", type=int, default=50, help="working scale; q0 has 10 bits more")
     ap.add_argument("--transform", choices=("dense", "fft"), default="dense")
     ap.add_argument("--groups", type=int, default=3, help="levels of each FFT-factored transform")
+    ap.add_argument("--slim", action="store_true", help="SlotToCoeff first, on the last levels (needs --transform fft)")
+    ap.add_argument("--s2c-groups", type=int, default=0, help="levels of SlotToCoeff (default: --groups)")
     ap.add_argument("--evalmod-bits", type=int, default=0, help="EvalMod working scale / primes (default: delta-bits)")
     args = ap.parse_args()
     n = 1 << args.log_n
@@ -31,7 +33,8 @@ def main():
     evalmod = [e] * (9 if args.log_n < 15 else 10)
     if args.transform == "fft":
         g = min(args.groups, args.slots.bit_length() - 1)
-        q_bits = [d + 10] + [d] * args.extra_levels + [d] * g + evalmod + [min(60, d + 8)] * g
+        g2 = min(args.s2c_groups or args.groups, args.slots.bit_length() - 1)
+        q_bits = [d + 10] + [d] * args.extra_levels + [d] * g2 + evalmod + [min(60, d + 8)] * g
     else:
         q_bits = [d + 10] + [d] * args.extra_levels + [d] + evalmod + [d, min(60, d + 18)]
     while len(q_bits) % args.alpha:
@@ -42,12 +45,12 @@ def main():
     ev = GpuEvaluator(pha, ctx, sk, args.slots)
     t0 = time.perf_counter()
     bs = Bootstrapper(ev, K=25 if args.log_n >= 15 else 12, r=3 if args.log_n < 15 else 4, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d,
-                      transform=args.transform, c2s_groups=args.groups, s2c_groups=args.groups)
+                      transform=args.transform, c2s_groups=args.groups, s2c_groups=args.s2c_groups or args.groups, slim=args.slim)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     rng = np.random.default_rng(2)
     msg = rng.uniform(-1, 1, args.slots) + 1j * rng.uniform(-1, 1, args.slots)
-    ct = ev.encrypt(ev.encode(msg, 2.0 ** d, ev.bottom))
+    ct = ev.encrypt(ev.encode(msg, 2.0 ** d, ev.bottom - bs.pre_levels))
     out = bs.bootstrap(ct)
     err = float(np.abs(ev.decrypt_decode(out) - msg).max())
     torch.cuda.synchronize()
@@ -58,7 +61,7 @@ def main():
         out = bs.bootstrap(ct)
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
-    print(json.dumps({"metric": "CKKS bootstrap ms", "transform": args.transform, "value": 1e3 * min(times), "unit": "ms", "log_n": args.log_n,
+    print(json.dumps({"metric": "CKKS bootstrap ms", "transform": args.transform, "order": "slim" if args.slim else "usual", "value": 1e3 * min(times), "unit": "ms", "log_n": args.log_n,
                       "slots": args.slots, "delta_bits": d, "evalmod_bits": e, "q_limbs": len(q_bits), "special_primes": args.alpha, "levels_after": ev.limbs(out.level) - 1,
                       "max_abs_error": err, "log_qp": round(float(sum(np.log2(np.array(mods, dtype=np.float64)))), 1), "setup_s": setup_s, "rotation_keys": len(ev.galois), "n_gpus": 1}), flush=True)
     ctx.close()
