@@ -184,6 +184,7 @@ class ChebyshevEvaluator:
         self.m = max(2 if optimal_depth else 1, math.ceil(math.log2(d + 1)))
         self.l = min(baby_log, self.m)
         self.optimal = optimal_depth
+        self.parallel = False       # evaluate the two halves of the top split (p = q T_h + r) with ev.run_pair
         assert not optimal_depth or self.l == 2
         self.depth = self.m if optimal_depth else self.m + 1
 
@@ -273,8 +274,16 @@ class ChebyshevEvaluator:
             qc[j - h] = 2.0 * c[j]
             r[2 * h - j] -= c[j]
         Th = self._at(h, level - 1)
-        qct = self._eval(qc, k - 1, level - 1, scale * ev.q_last(level - 1) / Th.scale)
-        rct = self._eval(r, k - 1, level, scale)
+        if self.parallel and k == self.m and k - 1 > self.l:
+            # two independent halves at 5-20 limbs each: side by side on the sibling (context, stream) pair
+            def other_half(e2):
+                twin = ChebyshevEvaluator(e2, self.c, self.l, self.optimal)
+                twin.T, twin._dropped, twin.L0 = self.T, {}, self.L0
+                return twin._eval(qc, k - 1, level - 1, scale * e2.q_last(level - 1) / Th.scale)
+            rct, qct = ev.run_pair(lambda e1: self._eval(r, k - 1, level, scale), other_half)
+        else:
+            qct = self._eval(qc, k - 1, level - 1, scale * ev.q_last(level - 1) / Th.scale)
+            rct = self._eval(r, k - 1, level, scale)
         if isinstance(qct, tuple):       # q is a constant: q*T_h is a plaintext multiple of T_h
             prod = ev.rescale(ev.mul_const(Th, qct[1], scale * ev.q_last(level - 1) / Th.scale))
         elif qct is None:

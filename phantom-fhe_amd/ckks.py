@@ -361,7 +361,9 @@ class GpuEvaluator(EvaluatorBase):
             b = fb(sib)
         a = fa(self)
         main.wait_stream(sib.stream)
-        b.data.record_stream(main)          # allocated on the sibling's stream, consumed on this one
+        for c in (b if isinstance(b, (list, tuple)) else [b]):
+            if isinstance(c, Ct):
+                c.data.record_stream(main)  # allocated on the sibling's stream, consumed on this one
         return a, b
 
 

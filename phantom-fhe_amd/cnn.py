@@ -31,6 +31,9 @@ import numpy as np
 from .bootstrap import ChebyshevEvaluator
 
 
+PARALLEL_CONV = os.environ.get("PHA_CONV_PARALLEL", "1") != "0"
+
+
 class TensorCipher:
     """A packed tensor: the ciphertext and (k, h, w, c, t, p) of `TensorCipher`, src/cnn_phantom.cu:3-60."""
     __slots__ = ("logn", "k", "h", "w", "c", "t", "p", "ct")
@@ -160,19 +163,29 @@ def multiplexed_parallel_convolution(ev, cache, name, x, co, st, fh, fw, data, r
     ocopy, oblk, o1, o2, ovalid = _coords(n, ko, ho, wo, to, 1)
     o_ch = ko * ko * oblk + ko * (o1 % ko) + o2 % ko
     bn_scale = constant_weight / np.sqrt(running_var + epsilon)
-    parts = []
-    for i9 in range(q):
-        out_ch = copy + pi * i9
-        acc = None
-        for (i1, i2), r in zip(taps, rots):
-            def make(out_ch=out_ch, i1=i1, i2=i2):
-                rr, cc = row + i1 - (fh - 1) // 2, col + i2 - (fw - 1) // 2
-                ok = valid & (out_ch < co) & (in_ch < ci) & (rr >= 0) & (rr < hi) & (cc >= 0) & (cc < wi)
-                return np.where(ok, W[np.minimum(out_ch, co - 1), np.minimum(in_ch, ci - 1), i1, i2], 0.0) if ok.any() else None
-            pt = cache.get((name, "w", i9, i1, i2), make, ev.q_last(level), level, n)
-            if pt is not None:
-                acc = ev.mul_plain_add(acc, r, pt)
-        parts.append(ev.rescale(acc))
+    def weighted_sums(e, first, last):
+        out = []
+        for i9 in range(first, last):
+            out_ch = copy + pi * i9
+            acc = None
+            for (i1, i2), r in zip(taps, rots):
+                def make(out_ch=out_ch, i1=i1, i2=i2):
+                    rr, cc = row + i1 - (fh - 1) // 2, col + i2 - (fw - 1) // 2
+                    ok = valid & (out_ch < co) & (in_ch < ci) & (rr >= 0) & (rr < hi) & (cc >= 0) & (cc < wi)
+                    return np.where(ok, W[np.minimum(out_ch, co - 1), np.minimum(in_ch, ci - 1), i1, i2], 0.0) if ok.any() else None
+                pt = cache.get((name, "w", i9, i1, i2), make, ev.q_last(level), level, n)
+                if pt is not None:
+                    acc = e.mul_plain_add(acc, r, pt)
+            out.append(e.rescale(acc))
+        return out
+    # once the constants are encoded, the two halves of the partial sums (and of the collection below) run side by
+    # side on the evaluator's sibling (context, stream) pair: kernels on 2-5 limbs leave most of the GPU idle
+    two = PARALLEL_CONV and q >= 2 and cache.store.get((name, "warm"), False)
+    if two:
+        a, b = ev.run_pair(lambda e: weighted_sums(e, 0, q // 2), lambda e: weighted_sums(e, q // 2, q))
+        parts = a + b
+    else:
+        parts = weighted_sums(ev, 0, q)
     # summation over the input channels (cnn_phantom.cu:499-537): the q partial sums rotate by the same steps, so
     # they move as one batch
     var = ev.batch(parts)
@@ -188,17 +201,27 @@ def multiplexed_parallel_convolution(ev, cache, name, x, co, st, fh, fw, data, r
         var = acc
     # collect the valid values into the output packing (cnn_phantom.cu:539-554): per partial sum one hoisted sum of
     # masked rotations (one modup, one moddown)
-    total = None
-    for i9, v in enumerate(ev.unbatch(var)):
-        js = [pi * i9 + i8 for i8 in range(pi) if pi * i9 + i8 < co]
-        steps = _rot_steps([(n // pi) * (j4 % pi) - j4 % ko - (j4 // (ko * ko)) * ko * ko * ho * wo - ((j4 % (ko * ko)) // ko) * ko * wo for j4 in js], n)
-        plains = []
-        for j4 in js:
-            def make_sel(j4=j4):
-                return np.where(ovalid & (o_ch == j4), bn_scale[j4], 0.0)
-            plains.append(cache.get((name, "sel", j4), make_sel, ev.q_last(level + 1), level + 1, n, lt=True))
-        part = ev.bsgs(v, steps, [0], [plains])
-        total = part if total is None else ev.add(total, part)
+    vs = ev.unbatch(var)
+
+    def collect(e, first, last):
+        total = None
+        for i9 in range(first, last):
+            js = [pi * i9 + i8 for i8 in range(pi) if pi * i9 + i8 < co]
+            steps = _rot_steps([(n // pi) * (j4 % pi) - j4 % ko - (j4 // (ko * ko)) * ko * ko * ho * wo - ((j4 % (ko * ko)) // ko) * ko * wo for j4 in js], n)
+            plains = []
+            for j4 in js:
+                def make_sel(j4=j4):
+                    return np.where(ovalid & (o_ch == j4), bn_scale[j4], 0.0)
+                plains.append(cache.get((name, "sel", j4), make_sel, ev.q_last(level + 1), level + 1, n, lt=True))
+            part = e.bsgs(vs[i9], steps, [0], [plains])
+            total = part if total is None else e.add(total, part)
+        return total
+    if two:
+        ta, tb = ev.run_pair(lambda e: collect(e, 0, q // 2), lambda e: collect(e, q // 2, q))
+        total = ev.add(ta, tb)
+    else:
+        total = collect(ev, 0, q)
+    cache.store[(name, "warm")] = True
     out = ev.rescale(total)
     if not end:
         out = _double_copies(ev, out, n, po)
@@ -394,6 +417,7 @@ class ApproxReLU:
 
     def __init__(self, degrees=(15, 15, 27), eps=None):
         self.degrees = tuple(degrees)
+        self.parallel = os.environ.get("PHA_RELU_PARALLEL", "1") != "0"   # the halves of every component on two streams
         if eps is None:
             best = None
             top = math.log2(float(np.prod(self.degrees)))      # the slope of the composite at 0 is below prod(degrees)
@@ -445,6 +469,7 @@ class ApproxReLU:
         last = len(self.scaled) - 1
         for i, coef in enumerate(self.scaled):
             cheb = ChebyshevEvaluator(ev, coef, baby_log=2, optimal_depth=True)
+            cheb.parallel = self.parallel
             if i == last:
                 y = cheb(y, ev.q_last(y.level + cheb.depth))       # (sign/2 + 1/2) * x then rescales back onto ct.scale
             else:
