@@ -274,11 +274,11 @@ class ChebyshevEvaluator:
             qc[j - h] = 2.0 * c[j]
             r[2 * h - j] -= c[j]
         Th = self._at(h, level - 1)
-        if self.parallel and k == self.m and k - 1 > self.l:
+        if self.parallel and k >= self.m - 1 and k > self.l:
             # two independent halves at 5-20 limbs each: side by side on the sibling (context, stream) pair
             def other_half(e2):
                 twin = ChebyshevEvaluator(e2, self.c, self.l, self.optimal)
-                twin.T, twin._dropped, twin.L0 = self.T, {}, self.L0
+                twin.T, twin._dropped, twin.L0, twin.parallel = self.T, {}, self.L0, self.parallel
                 return twin._eval(qc, k - 1, level - 1, scale * e2.q_last(level - 1) / Th.scale)
             rct, qct = ev.run_pair(lambda e1: self._eval(r, k - 1, level, scale), other_half)
         else:

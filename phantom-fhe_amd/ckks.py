@@ -334,32 +334,42 @@ class GpuEvaluator(EvaluatorBase):
         return Ct(self.ctx.mod_raise(a.data), 1, a.scale)
 
     # ---- a second (context, stream) pair for independent sub-circuits ---------------------------------------
-    def sibling(self):
+    def sibling(self, nest=0):
         """An evaluator with the same keys on its own library context (own workspace) and HIP stream: two
         independent sub-circuits at 15-30 limbs each fill less than half of the GPU, so running them side by
-        side nearly halves their time (measured: the two EvalMods of a full-slot bootstrap, 16.6 -> ... ms)."""
-        if getattr(self, "_sibling", None) is None:
+        side nearly halves their time (measured: the two EvalMods of a full-slot bootstrap, 16.6 -> ... ms).
+        One sibling per nesting depth of run_pair, so that nested pairs form a tree of streams."""
+        sibs = self.__dict__.setdefault("_siblings", {})
+        if nest not in sibs:
             import torch
             sib = GpuEvaluator.__new__(GpuEvaluator)
             EvaluatorBase.__init__(sib, self.log_n, self.q, self.s)
             sib.pha, sib.sk, sib.rlk, sib.galois = self.pha, self.sk, self.rlk, self.galois
             sib.ctx = self.pha.PhantomContext(self.ctx.log_n, self.ctx.moduli, self.ctx.size_P)
-            sib._seed, sib._mono, sib.auto_keys = self._seed + (1 << 20), {}, False
+            sib._seed, sib._mono, sib.auto_keys = self._seed + ((len(sibs) + 1) << 20), {}, False
             sib.double_hoisting, sib.baby_bias = self.double_hoisting, self.baby_bias
-            sib.merged_rescale, sib.concurrent_pairs = self.merged_rescale, False
-            sib.stream, sib._sibling = torch.cuda.Stream(), None
-            self._sibling = sib
-        return self._sibling
+            sib.merged_rescale, sib.concurrent_pairs = self.merged_rescale, self.concurrent_pairs
+            sib.stream = torch.cuda.Stream()
+            sib._nest = 0
+            sibs[nest] = sib
+        return sibs[nest]
+
+    MAX_NEST = 2          # run_pair inside run_pair: up to four streams
 
     def run_pair(self, fa, fb):
         import torch
-        if not self.concurrent_pairs:
+        nest = getattr(self, "_nest", 0)
+        if not self.concurrent_pairs or nest >= self.MAX_NEST:
             return fa(self), fb(self)
-        sib, main = self.sibling(), torch.cuda.current_stream()
+        sib, main = self.sibling(nest), torch.cuda.current_stream()
         sib.stream.wait_stream(main)
-        with torch.cuda.stream(sib.stream):
-            b = fb(sib)
-        a = fa(self)
+        self._nest, sib._nest = nest + 1, nest + 1
+        try:
+            with torch.cuda.stream(sib.stream):
+                b = fb(sib)
+            a = fa(self)
+        finally:
+            self._nest = nest
         main.wait_stream(sib.stream)
         for c in (b if isinstance(b, (list, tuple)) else [b]):
             if isinstance(c, Ct):

@@ -181,11 +181,14 @@ def multiplexed_parallel_convolution(ev, cache, name, x, co, st, fh, fw, data, r
     # once the constants are encoded, the two halves of the partial sums (and of the collection below) run side by
     # side on the evaluator's sibling (context, stream) pair: kernels on 2-5 limbs leave most of the GPU idle
     two = PARALLEL_CONV and q >= 2 and cache.store.get((name, "warm"), False)
-    if two:
-        a, b = ev.run_pair(lambda e: weighted_sums(e, 0, q // 2), lambda e: weighted_sums(e, q // 2, q))
-        parts = a + b
-    else:
-        parts = weighted_sums(ev, 0, q)
+    def fan_out(e, fn, join, first, last, depth):
+        """fn over [first, last) split over up to 2^depth evaluators (nested run_pair)"""
+        if depth == 0 or last - first < 2:
+            return fn(e, first, last)
+        mid = (first + last) // 2
+        a, b = e.run_pair(lambda e1: fan_out(e1, fn, join, first, mid, depth - 1), lambda e2: fan_out(e2, fn, join, mid, last, depth - 1))
+        return join(e, a, b)
+    parts = fan_out(ev, weighted_sums, lambda e, a, b: a + b, 0, q, 2 if two else 0)
     # summation over the input channels (cnn_phantom.cu:499-537): the q partial sums rotate by the same steps, so
     # they move as one batch
     var = ev.batch(parts)
@@ -216,11 +219,7 @@ def multiplexed_parallel_convolution(ev, cache, name, x, co, st, fh, fw, data, r
             part = e.bsgs(vs[i9], steps, [0], [plains])
             total = part if total is None else e.add(total, part)
         return total
-    if two:
-        ta, tb = ev.run_pair(lambda e: collect(e, 0, q // 2), lambda e: collect(e, q // 2, q))
-        total = ev.add(ta, tb)
-    else:
-        total = collect(ev, 0, q)
+    total = fan_out(ev, collect, lambda e, a, b: e.add(a, b), 0, q, 2 if two else 0)
     cache.store[(name, "warm")] = True
     out = ev.rescale(total)
     if not end:
@@ -610,6 +609,17 @@ class ResNetCifar10:
         import torch
         from .ckks import Ct
         static_in = TensorCipher(x.logn, x.k, x.h, x.w, x.c, x.t, x.p, Ct(x.ct.data.clone(), x.ct.level, x.ct.scale))
+        # pairs of streams only: ending the capture of a four-stream tree (nested run_pair) crashes inside hipGraph
+        # (ROCm 7.2); the graph is no faster than eager issue anyway
+        cls = type(self.ev)
+        nest, cls.MAX_NEST = cls.MAX_NEST, 1
+        try:
+            return self._capture(static_in)
+        finally:
+            cls.MAX_NEST = nest
+
+    def _capture(self, static_in):
+        import torch
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
