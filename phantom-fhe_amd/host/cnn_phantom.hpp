@@ -18,6 +18,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -107,7 +108,21 @@ public:
         return store_.emplace(key, std::move(pt)).first->second.get();
     }
     size_t size() const { return store_.size(); }
+    // a layer whose constants are all encoded may run its independent parts side by side
+    std::set<std::string> warm;
 };
+
+namespace cnn_detail {
+// fn over [first, last) split over up to 2^depth evaluators (nested run_pair)
+template <class R, class Fn, class Join>
+R fan_out(CKKSEvaluator &e, Fn &fn, Join &join, long first, long last, int depth) {
+    if (depth == 0 || last - first < 2) return fn(e, first, last);
+    const long mid = (first + last) / 2;
+    auto pr = e.run_pair([&](CKKSEvaluator &e1) { return fan_out<R>(e1, fn, join, first, mid, depth - 1); },
+                         [&](CKKSEvaluator &e2) { return fan_out<R>(e2, fn, join, mid, last, depth - 1); });
+    return join(e, pr.first, pr.second);
+}
+}  // namespace cnn_detail
 
 // ---- several ciphertexts of one (level, scale) in one buffer [batch][2][l][N] ----------------------------------------
 struct CipherBatch {
@@ -206,31 +221,42 @@ inline void multiplexed_parallel_convolution_phantom(CKKSEvaluator &ev, PlainCac
     for (int i1 = 0; i1 < fh; i1++)
         for (int i2 = 0; i2 < fw; i2++) tap_steps.push_back(mod_steps(static_cast<long>(ki) * ki * wi * (i1 - (fh - 1) / 2) + ki * (i2 - (fw - 1) / 2), n));
     std::vector<PhantomCiphertext> rots = ev.rotate_many(ct, tap_steps);
-    std::vector<PhantomCiphertext> parts;
-    for (long i9 = 0; i9 < q; i9++) {
-        PhantomCiphertext acc;
-        for (int i1 = 0; i1 < fh; i1++)
-            for (int i2 = 0; i2 < fw; i2++) {
-                // shifted weight vector (cnn_phantom.cu:382-401)
-                auto make = [&](std::vector<double> &v) {
-                    bool any = false;
-                    for (long j8 = 0; j8 < n; j8++) {
-                        const long pos = j8 % (n / pi), i8 = j8 / (n / pi);
-                        const long j5 = (pos % iblock) / (ki * wi), j6 = pos % (ki * wi), i7 = pos / iblock;
-                        const long in_ch = ki * ki * i7 + ki * (j5 % ki) + j6 % ki, out_ch = i8 + pi * i9;
-                        const long rr = j5 / ki - (fh - 1) / 2 + i1, cc = j6 / ki - (fw - 1) / 2 + i2;
-                        if (pos >= iblock * ti || out_ch >= co || in_ch >= ci || cc < 0 || cc > wi - 1 || rr < 0 || rr > hi - 1) continue;
-                        v[j8] = data[fh * fw * ci * out_ch + fh * fw * in_ch + fw * i1 + i2];
-                        any = true;
-                    }
-                    return any;
-                };
-                const PhantomPlaintext *pt = cache.get(ev, name + "/w/" + std::to_string(i9) + "/" + std::to_string(i1) + "/" + std::to_string(i2), make,
-                                                       ev.q_last(level), level, n);
-                if (pt) ev.mul_plain_add(acc, rots[i1 * fw + i2], *pt);
-            }
-        parts.push_back(ev.rescale(acc));
-    }
+    auto weighted_sums = [&](CKKSEvaluator &e, long first, long last) {
+        std::vector<PhantomCiphertext> out;
+        for (long i9 = first; i9 < last; i9++) {
+            PhantomCiphertext acc;
+            for (int i1 = 0; i1 < fh; i1++)
+                for (int i2 = 0; i2 < fw; i2++) {
+                    // shifted weight vector (cnn_phantom.cu:382-401)
+                    auto make = [&](std::vector<double> &v) {
+                        bool any = false;
+                        for (long j8 = 0; j8 < n; j8++) {
+                            const long pos = j8 % (n / pi), i8 = j8 / (n / pi);
+                            const long j5 = (pos % iblock) / (ki * wi), j6 = pos % (ki * wi), i7 = pos / iblock;
+                            const long in_ch = ki * ki * i7 + ki * (j5 % ki) + j6 % ki, out_ch = i8 + pi * i9;
+                            const long rr = j5 / ki - (fh - 1) / 2 + i1, cc = j6 / ki - (fw - 1) / 2 + i2;
+                            if (pos >= iblock * ti || out_ch >= co || in_ch >= ci || cc < 0 || cc > wi - 1 || rr < 0 || rr > hi - 1) continue;
+                            v[j8] = data[fh * fw * ci * out_ch + fh * fw * in_ch + fw * i1 + i2];
+                            any = true;
+                        }
+                        return any;
+                    };
+                    const PhantomPlaintext *pt = cache.get(ev, name + "/w/" + std::to_string(i9) + "/" + std::to_string(i1) + "/" + std::to_string(i2),
+                                                           make, ev.q_last(level), level, n);
+                    if (pt) e.mul_plain_add(acc, rots[i1 * fw + i2], *pt);
+                }
+            out.push_back(e.rescale(acc));
+        }
+        return out;
+    };
+    // once the constants are encoded, the halves of the partial sums (and of the collection below) run side by side
+    // on the evaluator's sibling (context, stream) pairs: kernels on 2-5 limbs leave most of the GPU idle
+    const int depth = cache.warm.count(name) ? 2 : 0;
+    auto concat = [](CKKSEvaluator &, std::vector<PhantomCiphertext> &a, std::vector<PhantomCiphertext> &b) {
+        for (auto &c : b) a.push_back(std::move(c));
+        return std::move(a);
+    };
+    std::vector<PhantomCiphertext> parts = fan_out<std::vector<PhantomCiphertext>>(ev, weighted_sums, concat, 0, q, depth);
     // summation over the input channels (cnn_phantom.cu:499-537): the q partial sums move as one batch
     CipherBatch var = CnnOps::gather(ev, parts);
     parts.clear();
@@ -255,30 +281,39 @@ inline void multiplexed_parallel_convolution_phantom(CKKSEvaluator &ev, PlainCac
         var = std::move(acc);
     }
     // collect the valid values into the output packing (cnn_phantom.cu:539-554); the masks carry the batch-norm factor
-    PhantomCiphertext total;
-    for (long i9 = 0; i9 < q; i9++) {
-        std::vector<int> steps;
-        std::vector<const PhantomPlaintext *> plains;
-        for (long i8 = 0; i8 < pi && pi * i9 + i8 < co; i8++) {
-            const long j4 = pi * i9 + i8;
-            steps.push_back(mod_steps((n / pi) * (j4 % pi) - j4 % ko - (j4 / (ko * ko)) * oblock - ((j4 % (ko * ko)) / ko) * ko * wo, n));
-            auto make = [&](std::vector<double> &v) {
-                const double f = constant_weight[j4] / std::sqrt(running_var[j4] + epsilon);
-                for (long u3 = 0; u3 < to; u3++)
-                    for (long v1 = 0; v1 < static_cast<long>(ko) * ho; v1++)
-                        for (long v2 = 0; v2 < static_cast<long>(ko) * wo; v2++)
-                            if (ko * ko * u3 + ko * (v1 % ko) + v2 % ko == j4) v[oblock * u3 + ko * wo * v1 + v2] = f;
-                return true;
-            };
-            plains.push_back(cache.get(ev, name + "/sel/" + std::to_string(j4), make, ev.q_last(level + 1), level + 1, n, true));
+    auto collect = [&](CKKSEvaluator &e, long first, long last) {
+        PhantomCiphertext total;
+        for (long i9 = first; i9 < last; i9++) {
+            std::vector<int> steps;
+            std::vector<const PhantomPlaintext *> plains;
+            for (long i8 = 0; i8 < pi && pi * i9 + i8 < co; i8++) {
+                const long j4 = pi * i9 + i8;
+                steps.push_back(mod_steps((n / pi) * (j4 % pi) - j4 % ko - (j4 / (ko * ko)) * oblock - ((j4 % (ko * ko)) / ko) * ko * wo, n));
+                auto make = [&](std::vector<double> &v) {
+                    const double f = constant_weight[j4] / std::sqrt(running_var[j4] + epsilon);
+                    for (long u3 = 0; u3 < to; u3++)
+                        for (long v1 = 0; v1 < static_cast<long>(ko) * ho; v1++)
+                            for (long v2 = 0; v2 < static_cast<long>(ko) * wo; v2++)
+                                if (ko * ko * u3 + ko * (v1 % ko) + v2 % ko == j4) v[oblock * u3 + ko * wo * v1 + v2] = f;
+                    return true;
+                };
+                plains.push_back(cache.get(ev, name + "/sel/" + std::to_string(j4), make, ev.q_last(level + 1), level + 1, n, true));
+            }
+            PhantomCiphertext v = CnnOps::take(e, var, i9);
+            PhantomCiphertext part = e.bsgs(v, steps, {0}, plains);
+            if (total.data() == nullptr)
+                total = std::move(part);
+            else
+                e.add_inplace(total, part);
         }
-        PhantomCiphertext v = CnnOps::take(ev, var, i9);
-        PhantomCiphertext part = ev.bsgs(v, steps, {0}, plains);
-        if (total.data() == nullptr)
-            total = std::move(part);
-        else
-            ev.add_inplace(total, part);
-    }
+        return total;
+    };
+    auto sum = [](CKKSEvaluator &e, PhantomCiphertext &a, PhantomCiphertext &b) {
+        e.add_inplace(a, b);
+        return std::move(a);
+    };
+    PhantomCiphertext total = fan_out<PhantomCiphertext>(ev, collect, sum, 0, q, depth);
+    cache.warm.insert(name);
     PhantomCiphertext out = ev.rescale(total);
     if (!end) out = CnnOps::double_copies(ev, std::move(out), n, po);
     cnn_out = TensorCipher(logn, ko, ho, wo, co, to, end ? 1 : static_cast<int>(po), std::move(out));
@@ -442,6 +477,7 @@ public:
     std::vector<double> bounds, errors;
     double eps = 0, precision = 0;
     int depth = 0;
+    bool parallel = true;  // the halves of every component polynomial on sibling streams (ChebyshevEvaluator::parallel)
 
 private:
     static double cheb_eval(const std::vector<double> &c, double x) {  // Clenshaw
@@ -613,6 +649,7 @@ public:
         PhantomCiphertext y = ct.clone(ev.stream.get_stream());
         for (size_t i = 0; i < scaled.size(); i++) {
             ChebyshevEvaluator cheb(&ev, scaled[i], 2, true);
+            cheb.parallel = parallel;
             const bool last = i + 1 == scaled.size();
             // the last component lands on the scale q_last: (sign/2 + 1/2) * x then rescales back onto ct.scale
             y = cheb(y, last ? ev.q_last(y.chain_index() + cheb.depth()) : y.scale());

@@ -53,9 +53,13 @@ public:
 private:
     std::map<std::tuple<double, double, double, size_t>, PhantomPlaintext> consts_;
     std::map<size_t, device_words> mono_;
-    std::unique_ptr<PhantomContext> sibling_context_;
-    std::unique_ptr<CKKSEvaluator> sibling_;
-    hipEvent_t fork_ = nullptr, join_ = nullptr;
+    struct Sibling {
+        std::unique_ptr<PhantomContext> context;
+        std::unique_ptr<CKKSEvaluator> ev;
+        hipEvent_t fork = nullptr, join = nullptr;
+    };
+    std::map<int, Sibling> siblings_;
+    int nest_ = 0;
     const hipStream_t &s() const { return stream.get_stream(); }
     pha_context *h() const { return context->handle(); }
     static void same(const PhantomCiphertext &a, const PhantomCiphertext &b) {
@@ -76,31 +80,57 @@ public:
           scale(scale_) {}
 
     ~CKKSEvaluator() {
-        if (fork_) (void)hipEventDestroy(fork_);
-        if (join_) (void)hipEventDestroy(join_);
+        for (auto &sb : siblings_) {
+            if (sb.second.fork) (void)hipEventDestroy(sb.second.fork);
+            if (sb.second.join) (void)hipEventDestroy(sb.second.join);
+        }
     }
     // An evaluator with the same keys on its own library context (own workspace) and HIP stream.  Two independent
     // sub-circuits at 15-30 limbs each fill less than half of the GPU: side by side they take little more than one.
-    CKKSEvaluator &sibling() {
-        if (!sibling_) {
-            sibling_context_ = std::make_unique<PhantomContext>(context->key_parms());
-            sibling_ = std::make_unique<CKKSEvaluator>(sibling_context_.get(), secret_key, encoder, relin_keys, galois_keys, scale);
-            check_hip(hipEventCreateWithFlags(&fork_, hipEventDisableTiming), "hipEventCreate");
-            check_hip(hipEventCreateWithFlags(&join_, hipEventDisableTiming), "hipEventCreate");
+    // One sibling per nesting depth of run_pair, so that nested pairs form a tree of streams.
+    CKKSEvaluator &sibling(int nest = 0) {
+        auto it = siblings_.find(nest);
+        if (it == siblings_.end()) {
+            Sibling sb;
+            sb.context = std::make_unique<PhantomContext>(context->key_parms());
+            sb.ev = std::make_unique<CKKSEvaluator>(sb.context.get(), secret_key, encoder, relin_keys, galois_keys, scale);
+            check_hip(hipEventCreateWithFlags(&sb.fork, hipEventDisableTiming), "hipEventCreate");
+            check_hip(hipEventCreateWithFlags(&sb.join, hipEventDisableTiming), "hipEventCreate");
+            it = siblings_.emplace(nest, std::move(sb)).first;
         }
-        return *sibling_;
+        return *it->second.ev;
     }
-    // (fa(*this), fb(sibling())) concurrently; both results are usable on this evaluator's stream afterwards
+    static void adopt(PhantomCiphertext &c, const hipStream_t &st) { c.touch(st); }
+    static void adopt(std::vector<PhantomCiphertext> &v, const hipStream_t &st) {
+        for (auto &c : v) c.touch(st);
+    }
+    template <class T>
+    static auto adopt(T &v, const hipStream_t &st) -> decltype(v.adopt(st)) {
+        return v.adopt(st);
+    }
+    static constexpr int kMaxNest = 2;  // run_pair inside run_pair: up to four streams
+    // (fa(*this), fb(sibling)) concurrently; both results are usable on this evaluator's stream afterwards
     template <class FA, class FB>
-    std::pair<PhantomCiphertext, PhantomCiphertext> run_pair(FA &&fa, FB &&fb) {
-        CKKSEvaluator &sib = sibling();
-        check_hip(hipEventRecord(fork_, s()), "hipEventRecord");
-        check_hip(hipStreamWaitEvent(sib.s(), fork_, 0), "hipStreamWaitEvent");
-        PhantomCiphertext b = fb(sib);
-        check_hip(hipEventRecord(join_, sib.s()), "hipEventRecord");
-        PhantomCiphertext a = fa(*this);
-        check_hip(hipStreamWaitEvent(s(), join_, 0), "hipStreamWaitEvent");
-        b.touch(s());  // allocated on the sibling's stream, consumed (and released) on this one
+    auto run_pair(FA &&fa, FB &&fb) -> std::pair<decltype(fa(*this)), decltype(fb(*this))> {
+        if (nest_ >= kMaxNest) {
+            auto a0 = fa(*this);
+            auto b0 = fb(*this);
+            return {std::move(a0), std::move(b0)};
+        }
+        const int nest = nest_;
+        CKKSEvaluator &sib = sibling(nest);
+        Sibling &sb = siblings_.at(nest);
+        check_hip(hipEventRecord(sb.fork, s()), "hipEventRecord");
+        check_hip(hipStreamWaitEvent(sib.s(), sb.fork, 0), "hipStreamWaitEvent");
+        sib.nest_ = nest + 1;
+        sib.auto_keys = false;
+        auto b = fb(sib);
+        check_hip(hipEventRecord(sb.join, sib.s()), "hipEventRecord");
+        nest_ = nest + 1;
+        auto a = fa(*this);
+        nest_ = nest;
+        check_hip(hipStreamWaitEvent(s(), sb.join, 0), "hipStreamWaitEvent");
+        adopt(b, s());  // allocated on the sibling's stream, consumed (and released) on this one
         return {std::move(a), std::move(b)};
     }
 
@@ -515,10 +545,12 @@ class ChebyshevEvaluator {
     int m_, l_;
     bool optimal_ = false;  // depth ceil(log2(d+1)): a leaf c1 T1 + c2 T2 + c3 T3 is (c1 - c3) T1 + c2 T2 + (2 c3 T1) T2
     std::map<int, PhantomCiphertext> T_;
+    const std::map<int, PhantomCiphertext> *Tp_ = nullptr;  // a twin on a sibling evaluator reads its parent's powers
     std::map<std::pair<int, size_t>, PhantomCiphertext> dropped_;
+    const std::map<int, PhantomCiphertext> &powers_ref() const { return Tp_ ? *Tp_ : T_; }
     // T_j at `level` (dropping limbs copies the ciphertext: once per level)
     const PhantomCiphertext &at(int j, size_t level) {
-        const PhantomCiphertext &t = T_.at(j);
+        const PhantomCiphertext &t = powers_ref().at(j);
         if (t.chain_index() == level) return t;
         auto key = std::make_pair(j, level);
         auto it = dropped_.find(key);
@@ -530,6 +562,9 @@ class ChebyshevEvaluator {
         enum Kind { NONE, CONST, CT } kind = NONE;
         double c = 0;
         PhantomCiphertext ct;
+        void adopt(const hipStream_t &st) {
+            if (kind == CT) ct.touch(st);
+        }
     };
     static void trim(std::vector<double> &c) {
         while (!c.empty() && c.back() == 0.0) c.pop_back();
@@ -612,8 +647,19 @@ class ChebyshevEvaluator {
         }
         const PhantomCiphertext &Th = at(static_cast<int>(hh), level - 1);
         const double qscale = scale * ev_->q_last(level - 1) / Th.scale();
-        Val qv = eval(std::move(qc), k - 1, level - 1, qscale);
-        Val rv = eval(std::move(r), k - 1, level, scale);
+        Val qv, rv;
+        if (parallel && k >= m_ - 1 && k > l_) {
+            // two independent halves at 5-20 limbs each: side by side on the sibling (context, stream) pair
+            auto pr = ev_->run_pair([&](CKKSEvaluator &) { return eval(r, k - 1, level, scale); },
+                                    [&](CKKSEvaluator &e2) {
+                                        ChebyshevEvaluator twin(&e2, *this);
+                                        return twin.eval(qc, k - 1, level - 1, qscale);
+                                    });
+            rv = std::move(pr.first), qv = std::move(pr.second);
+        } else {
+            qv = eval(std::move(qc), k - 1, level - 1, qscale);
+            rv = eval(std::move(r), k - 1, level, scale);
+        }
         Val prod;
         if (qv.kind == Val::CONST) {
             prod.kind = Val::CT;
@@ -632,7 +678,11 @@ class ChebyshevEvaluator {
     }
 
 public:
+    bool parallel = false;  // the two halves of the top splits (p = q T_h + r) through ev.run_pair
     ChebyshevEvaluator() : ev_(nullptr), m_(1), l_(1) {}
+    // the same polynomial on another evaluator, reading `parent`'s powers
+    ChebyshevEvaluator(CKKSEvaluator *ev, const ChebyshevEvaluator &parent)
+        : ev_(ev), c_(parent.c_), m_(parent.m_), l_(parent.l_), optimal_(parent.optimal_), Tp_(&parent.powers_ref()), parallel(parent.parallel) {}
     ChebyshevEvaluator(CKKSEvaluator *ev, std::vector<double> coeffs, int baby_log = 2, bool optimal_depth = false)
         : ev_(ev), c_(std::move(coeffs)), optimal_(optimal_depth) {
         const double d = static_cast<double>(c_.size()) - 1.0;
