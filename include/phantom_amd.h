@@ -304,7 +304,10 @@ int pha_multiply_relin_rescale(pha_context *ctx, size_t chain_index, const uint6
 
 /* apply_galois_inplace (src/evaluate.cu:747-794) on `batch` independent ciphertexts sharing the Galois element and
  * its key: in / out are [batch][2][l][N] contiguous, out of place (BASELINE configs[3], rotate x 64).  Results are
- * bit-identical to `batch` calls of pha_apply_galois_inplace; the reference has no batched entry point. */
+ * bit-identical to `batch` calls of pha_apply_galois_inplace; the reference has no batched entry point.  Levels whose
+ * digits are uniform (alpha divides l) or that hold a single short digit (l < alpha: the 1-3 limb ciphertexts of the
+ * CNN's convolutions) run kernels that span the batch; alpha = 1 and several digits with a ragged last one fall back to
+ * one ciphertext at a time. */
 int pha_apply_galois_batched(pha_context *ctx, size_t chain_index, const uint64_t *in, uint64_t *out, size_t batch,
                              uint32_t galois_elt, const uint64_t *const *galois_evks, pha_stream_t stream);
 

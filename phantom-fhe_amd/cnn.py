@@ -160,7 +160,7 @@ def multiplexed_parallel_convolution(ev, cache, name, x, co, st, fh, fw, data, r
     rots = ev.rotate_many(ct, _rot_steps([ki * ki * wi * (i1 - (fh - 1) // 2) + ki * (i2 - (fw - 1) // 2) for i1, i2 in taps], n))
     d, c = _log2(ki), _log2(ti)
     # selection masks of the output packing, carrying the batch-norm factor (cnn_phantom.cu:403-434)
-    ocopy, oblk, o1, o2, ovalid = _coords(n, ko, ho, wo, to, 1)
+    _, oblk, o1, o2, ovalid = _coords(n, ko, ho, wo, to, 1)
     o_ch = ko * ko * oblk + ko * (o1 % ko) + o2 % ko
     bn_scale = constant_weight / np.sqrt(running_var + epsilon)
     def weighted_sums(e, first, last):
