@@ -302,6 +302,15 @@ int pha_rotate_hoisted(pha_context *ctx, size_t chain_index, const uint64_t *ct,
 int pha_multiply_relin_rescale(pha_context *ctx, size_t chain_index, const uint64_t *ct1, const uint64_t *ct2,
                                const uint64_t *const *relin_evks, uint64_t *out, int times2, pha_stream_t stream);
 
+/* `batch` independent pha_multiply_relin_rescale products at one level, one launch sequence: ct1s / ct2s are host arrays
+ * of device pointers ([2][l][N] each; ct1s[b] == ct2s[b] squares), outs is [batch][2][l-1][N] contiguous.  Bit-identical
+ * to `batch` single calls; the transforms and base conversions span the batch and the relinearisation key is read once
+ * per four products (the leaves and the same-height products of a Paterson-Stockmeyer polynomial evaluation).  The
+ * reference has no counterpart. */
+int pha_multiply_relin_rescale_batched(pha_context *ctx, size_t chain_index, size_t batch, const uint64_t *const *ct1s,
+                                       const uint64_t *const *ct2s, const uint64_t *const *relin_evks, uint64_t *outs, int times2,
+                                       pha_stream_t stream);
+
 /* apply_galois_inplace (src/evaluate.cu:747-794) on `batch` independent ciphertexts sharing the Galois element and
  * its key: in / out are [batch][2][l][N] contiguous, out of place (BASELINE configs[3], rotate x 64).  Results are
  * bit-identical to `batch` calls of pha_apply_galois_inplace; the reference has no batched entry point.  Levels whose

@@ -94,6 +94,7 @@ SIGNATURES = {
     "pha_ckks_decode": (_int, [_vp, _vp, _sz, ctypes.c_double, _sz, _vp, _vp]),
     "pha_rotate_hoisted": (_int, [_vp, _sz, _vp, _sz, _u32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
     "pha_multiply_relin_rescale": (_int, [_vp, _sz, _vp, _vp, _vp, _vp, _int, _vp]),
+    "pha_multiply_relin_rescale_batched": (_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _int, _vp]),
     "pha_apply_galois_batched": (_int, [_vp, _sz, _vp, _vp, _sz, _u32, _vp, _vp]),
     "pha_ckks_encode_qp": (_int, [_vp, _vp, _sz, _sz, _sz, ctypes.c_double, _vp, _vp]),
     "pha_linear_transform_double_hoisted": (_int, [_vp, _sz, _vp, _sz, _u32p, ctypes.POINTER(_vp), _sz, _u32p, ctypes.POINTER(_vp),
@@ -491,6 +492,16 @@ class PhantomContext:
         out = self._empty(2, ct1.shape[1] - 1)
         _check(lib().pha_multiply_relin_rescale(self._h, chain_index, _ptr(ct1), _ptr(ct2), relin_key.ptr, _ptr(out),
                                                 1 if times2 else 0, _stream()))
+        return out
+
+    def multiply_relin_rescale_batched(self, chain_index, ct1s, ct2s, relin_key, times2=False):
+        """len(ct1s) independent multiply_relin_rescale products at one level in one launch sequence; out [batch][2][l-1][N]"""
+        import torch
+        b = len(ct1s)
+        out = torch.empty((b, 2, ct1s[0].shape[1] - 1, self.n), dtype=torch.int64, device=ct1s[0].device)
+        p1, p2 = (_vp * b)(*[t.data_ptr() for t in ct1s]), (_vp * b)(*[t.data_ptr() for t in ct2s])
+        _check(lib().pha_multiply_relin_rescale_batched(self._h, chain_index, b, p1, p2, relin_key.ptr, _ptr(out), 1 if times2 else 0,
+                                                        _stream()))
         return out
 
     def apply_galois_batched(self, chain_index, cts, galois_elt, galois_key):

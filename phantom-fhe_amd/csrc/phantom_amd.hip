@@ -1996,6 +1996,58 @@ int pha_multiply_relin_rescale(pha_context *ctx, size_t chain_index, const uint6
     return do_merged_moddown(ctx, lt, out, cx, scratch, 2, false, st);
 }
 
+// `batch` independent products at one level in one launch sequence: outs [batch][2][l-1][N] contiguous,
+// out[b] = pha_multiply_relin_rescale(ct1s[b], ct2s[b]) bit for bit.  The transforms, the base conversions and the
+// inner product span the batch (the relinearisation key is read once per four products); levels whose digits are
+// neither uniform nor a single short one fall back to one product at a time.
+int pha_multiply_relin_rescale_batched(pha_context *ctx, size_t chain_index, size_t batch, const uint64_t *const *ct1s,
+                                       const uint64_t *const *ct2s, const uint64_t *const *relin_evks, uint64_t *outs, int times2,
+                                       pha_stream_t stream) {
+    REQUIRE_CTX(ct1s && ct2s && relin_evks && outs);
+    if (batch == 0) return PHA_OK;
+    LevelTool *lt;
+    PHA_TRY(get_level(ctx, chain_index, &lt));
+    const size_t n = ctx->n, size_Ql = lt->size_Ql, size_QlP = size_Ql + ctx->size_P;
+    if (size_Ql < 2) return fail(PHA_ERR_INVALID_ARGUMENT, "end of modulus switching chain reached");
+    const size_t out_words = 2 * (size_Ql - 1) * n;
+    if (batch == 1 || (!lt->uniform_digits && !(ctx->size_P > 1 && lt->beta == 1))) {
+        for (size_t b = 0; b < batch; b++)
+            PHA_TRY(pha_multiply_relin_rescale(ctx, chain_index, ct1s[b], ct2s[b], relin_evks, outs + b * out_words, times2, stream));
+        return PHA_OK;
+    }
+    hipStream_t st = as_stream(stream);
+    if (!ctx->d_bigP_mod_q.p) {
+        LevelConstants lc;
+        build_level_constants(ctx->moduli, ctx->size_P, ctx->size_Q, lc);
+        HIP_TRY(ctx->d_bigP_mod_q.upload(lc.bigP_mod_q));
+    }
+    // workspace: t_mod_up [batch][beta][QlP] | cx [batch][2][QlP] | d [batch][3][Ql] | t_cks [batch][3][Ql] (third slots used) |
+    // delta [2 batch][Ql]
+    const size_t d_words = 3 * size_Ql * n;
+    uint64_t *ws;
+    PHA_TRY(ensure_workspace(ctx, batch * (lt->beta * size_QlP + 2 * size_QlP + 2 * 3 * size_Ql + 2 * size_Ql) * n, &ws));
+    uint64_t *t_mod_up = ws, *cx = t_mod_up + batch * lt->beta * size_QlP * n, *d = cx + batch * 2 * size_QlP * n,
+             *t_cks = d + batch * d_words, *delta = t_cks + batch * d_words;
+    const uint32_t n32 = static_cast<uint32_t>(n), ql = static_cast<uint32_t>(size_Ql), qlp = static_cast<uint32_t>(size_QlP);
+    const dim3 tg(ql * (n32 / 512));
+    for (size_t b = 0; b < batch; b++) {
+        if (ct1s[b] == ct2s[b])
+            hipLaunchKernelGGL((tensor_prod_2x2_kernel<true>), tg, dim3(256), 0, st, ct1s[b], ct1s[b], ctx->d_mod.p, d + b * d_words, n32, ql,
+                               times2 ? 1u : 0u);
+        else
+            hipLaunchKernelGGL((tensor_prod_2x2_kernel<false>), tg, dim3(256), 0, st, ct1s[b], ct2s[b], ctx->d_mod.p, d + b * d_words, n32, ql,
+                               times2 ? 1u : 0u);
+    }
+    PHA_TRY(check_launch("tensor_prod_2x2"));
+    PHA_TRY(do_modup_batched(ctx, lt, t_mod_up, d + 2 * size_Ql * n, t_cks + 2 * size_Ql * n, d_words, batch, st));
+    PHA_TRY(do_inner_prod_batched(ctx, lt, cx, t_mod_up, relin_evks, batch, st));
+    for (size_t b = 0; b < batch; b++)
+        hipLaunchKernelGGL((lift_qp_kernel<false>), dim3(qlp * (n32 / 512), 2), dim3(256), 0, st, cx + b * 2 * size_QlP * n, d + b * d_words,
+                           static_cast<const uint32_t *>(nullptr), ctx->d_bigP_mod_q.p, ctx->d_mod.p, n32, ql, qlp);
+    PHA_TRY(check_launch("lift_qp"));
+    return do_merged_moddown(ctx, lt, outs, cx, delta, 2 * batch, false, st);
+}
+
 // ---- bootstrapping primitives (src/boot/Bootstrapper.cu) ------------------------------------------
 int pha_mod_raise(pha_context *ctx, const uint64_t *src, uint64_t *dst, pha_stream_t stream) {
     REQUIRE_CTX(src && dst);

@@ -441,3 +441,24 @@ def test_hoisted_rotations(gpu, pha, orc, size_p, chain_index):
     with pytest.raises(pha.PhantomError):
         ctx.rotate_hoisted(chain_index, pha.to_device(ct), [4], keys_d[:1])   # even Galois element
     ctx.close()
+
+
+@pytest.mark.parametrize("size_p,chain_index,batch", [(2, 1, 3), (2, 3, 5), (3, 1, 4), (3, 5, 4), (3, 3, 2), (1, 2, 3)])
+def test_batched_multiply_relin_rescale_equals_single_calls(gpu, pha, orc, size_p, chain_index, batch):
+    """pha_multiply_relin_rescale_batched = `batch` x pha_multiply_relin_rescale, bit for bit (and so the oracle's
+    restatement): uniform digits, a single short digit, and the per-product fallback; products, a shared right
+    operand and a square in one batch"""
+    import torch
+    mods = orc.coeff_modulus_create(4096, [45] * 6 + [55] * size_p)
+    ctx, o = pha.PhantomContext(12, mods, size_p), orc.Oracle(12, mods, size_p)
+    size_ql = ctx.size_Ql(chain_index)
+    tq = list(range(size_ql))
+    _, evk_d = _uniform_evk(pha, o, 720)
+    a = [_dev(pha, np.stack([o.uniform_poly(tq, 730 + 2 * b), o.uniform_poly(tq, 731 + 2 * b)])) for b in range(batch)]
+    shared = _dev(pha, np.stack([o.uniform_poly(tq, 760), o.uniform_poly(tq, 761)]))
+    right = [shared] * (batch - 1) + [a[-1]]                      # the last one is a square
+    for times2 in (False, True):
+        out = ctx.multiply_relin_rescale_batched(chain_index, a, right, evk_d, times2)
+        for b in range(batch):
+            assert torch.equal(out[b], ctx.multiply_relin_rescale(chain_index, a[b], right[b], evk_d, times2))
+    ctx.close()
