@@ -185,6 +185,7 @@ class ChebyshevEvaluator:
         self.l = min(baby_log, self.m)
         self.optimal = optimal_depth
         self.parallel = False       # evaluate the two halves of the top split (p = q T_h + r) with ev.run_pair
+        self.batched = False        # optimal depth only: all nodes of one height at one level, as batched products
         assert not optimal_depth or self.l == 2
         self.depth = self.m if optimal_depth else self.m + 1
 
@@ -225,7 +226,90 @@ class ChebyshevEvaluator:
         self.L0 = w.level
         level = self.L0 + self.depth
         scale = w.scale if target_scale is None else target_scale
+        if self.batched and self.optimal:
+            return self._eval_by_height(scale)
         return self._eval(self.c, self.m, level, scale)
+
+    # ---- the same recursion, evaluated height by height ---------------------------------------------------------
+    def _plan(self, c, k, scale):
+        """tree of the Paterson-Stockmeyer recursion with every node of height k placed at level L0 + k (the earliest
+        it can be computed): nodes of one height are independent products at one level"""
+        ev = self.ev
+        c = np.trim_zeros(np.asarray(c, dtype=np.float64), "b")
+        if len(c) == 0:
+            return None
+        if k <= self.l or len(c) <= (1 << self.l):
+            return {"kind": "leaf", "c": c[:1 << self.l], "height": self.l, "scale": scale}
+        h = 1 << (k - 1)
+        if len(c) <= h:
+            return self._plan(c, k - 1, scale)
+        qc = np.zeros(len(c) - h)
+        r = np.array(c[:h], dtype=np.float64)
+        qc[0] = c[h]
+        for j in range(h + 1, len(c)):
+            qc[j - h] = 2.0 * c[j]
+            r[2 * h - j] -= c[j]
+        Th = self._at(h, self.L0 + k - 1)
+        return {"kind": "node", "height": k, "scale": scale, "Th": Th,
+                "q": self._plan(qc, k - 1, scale * ev.q_last(self.L0 + k - 1) / Th.scale), "r": self._plan(r, k - 1, scale)}
+
+    def _eval_by_height(self, scale):
+        ev = self.ev
+        root = self._plan(self.c, self.m, scale)
+        nodes = []
+
+        def walk(nd):
+            if nd is not None:
+                nodes.append(nd)
+                if nd["kind"] == "node":
+                    walk(nd["q"])
+                    walk(nd["r"])
+        walk(root)
+        # leaves: odd ones (2 c3 T1)(T2 + kappa) as ONE batch of products at level L0 + 1, the others one by one
+        lvl = self.L0 + self.l - 1
+        q = ev.q_last(lvl)
+        batch = []
+        for nd in nodes:
+            if nd["kind"] != "leaf":
+                continue
+            c = nd["c"]
+            if len(c) > 3 and abs(c[3]) >= 1e-300 and abs(c[2]) < 1e-300 and abs((c[1] - c[3]) / (2.0 * c[3])) <= 16.0:
+                t1, t2 = self._at(1, lvl - 1), self._at(2, lvl)
+                a = ev.rescale(ev.mul_const(t1, 2.0 * c[3], (nd["scale"] * q / t2.scale) * ev.q_last(lvl - 1) / t1.scale))
+                batch.append((nd, a, ev.add_const(t2, (c[1] - c[3]) / (2.0 * c[3]))))
+            else:
+                nd["val"] = self._leaf(c, self.L0 + self.l, nd["scale"])
+        for (nd, _, _), out in zip(batch, ev.mul_rescale_batch([(a, b) for _, a, b in batch])):
+            nd["val"] = ev.add_const(out, nd["c"][0]) if abs(nd["c"][0]) >= 1e-300 else out
+
+        def at_level(v, level):
+            return ev.drop(v, level) if isinstance(v, type(self.T[1])) and v.level < level else v
+        for k in range(self.l + 1, self.m + 1):
+            todo = [nd for nd in nodes if nd["kind"] == "node" and nd["height"] == k]
+            pairs, owners = [], []
+            for nd in todo:
+                qv = None if nd["q"] is None else nd["q"]["val"]
+                if isinstance(qv, tuple):            # q is a constant: a plaintext multiple of T_h
+                    nd["prod"] = ev.rescale(ev.mul_const(nd["Th"], qv[1], nd["q"]["scale"]))
+                elif qv is None:
+                    nd["prod"] = None
+                else:
+                    pairs.append((at_level(qv, self.L0 + k - 1), nd["Th"]))
+                    owners.append(nd)
+            for nd, out in zip(owners, ev.mul_rescale_batch(pairs)):
+                nd["prod"] = out
+            for nd in todo:
+                prod, rv = nd["prod"], (None if nd["r"] is None else nd["r"]["val"])
+                if prod is None:
+                    nd["val"] = rv if rv is None or isinstance(rv, tuple) else at_level(rv, self.L0 + k)
+                elif rv is None:
+                    nd["val"] = prod
+                elif isinstance(rv, tuple):
+                    nd["val"] = ev.add_const(prod, rv[1])
+                else:
+                    nd["val"] = ev.add(prod, at_level(rv, self.L0 + k))
+        out = root["val"]
+        return at_level(out, self.L0 + self.depth)
 
     def _leaf(self, c, level, scale):
         """sum_j c_j T_j, j < 2^l, landing exactly on (level, scale)"""

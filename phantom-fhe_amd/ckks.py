@@ -128,6 +128,10 @@ class EvaluatorBase:
         t = self.mul(a, b)
         return self.rescale(self.double(t) if times2 else t)
 
+    def mul_rescale_batch(self, pairs, times2=False):
+        """[rescale(a * b) for a, b in pairs], all at one level: back ends may run them as one launch sequence"""
+        return [self.mul_rescale(a, b, times2) for a, b in pairs]
+
     def square_double_minus_one(self, a):
         """2a^2 - 1 (a Chebyshev doubling / a cosine double angle), one level"""
         return self.add_const(self.mul_rescale(a, a, times2=True), -1.0)
@@ -284,6 +288,16 @@ class GpuEvaluator(EvaluatorBase):
         assert a.level == b.level
         out = self.ctx.multiply_relin_rescale(a.level, a.data, b.data, self.rlk, times2)
         return Ct(out, a.level + 1, a.scale * b.scale / self.q_last(a.level))
+
+    def mul_rescale_batch(self, pairs, times2=False):
+        """one C-ABI call: pha_multiply_relin_rescale_batched"""
+        if not self.merged_rescale or len(pairs) < 2:
+            return super().mul_rescale_batch(pairs, times2)
+        level = pairs[0][0].level
+        assert all(a.level == level and b.level == level for a, b in pairs)
+        out = self.ctx.multiply_relin_rescale_batched(level, [a.data for a, _ in pairs], [b.data for _, b in pairs], self.rlk, times2)
+        q = self.q_last(level)
+        return [Ct(out[i], level + 1, a.scale * b.scale / q) for i, (a, b) in enumerate(pairs)]
 
     def rescale(self, a):
         import torch

@@ -420,6 +420,7 @@ class ApproxReLU:
     def __init__(self, degrees=(15, 15, 27), eps=None):
         self.degrees = tuple(degrees)
         eps = self._known_eps.get(self.degrees) if eps is None else eps
+        self.batched = os.environ.get("PHA_RELU_BATCHED", "0") != "0"     # nodes of one height as one batched product
         self.parallel = os.environ.get("PHA_RELU_PARALLEL", "1") != "0"   # the halves of every component on two streams
         if eps is None:
             best = None
@@ -473,6 +474,7 @@ class ApproxReLU:
         for i, coef in enumerate(self.scaled):
             cheb = ChebyshevEvaluator(ev, coef, baby_log=2, optimal_depth=True)
             cheb.parallel = self.parallel
+            cheb.batched = self.batched
             if i == last:
                 y = cheb(y, ev.q_last(y.level + cheb.depth))       # (sign/2 + 1/2) * x then rescales back onto ct.scale
             else:

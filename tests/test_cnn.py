@@ -217,3 +217,18 @@ def test_resnet8_with_bootstrapping_on_the_gpu(slim):
     assert np.array_equal(again, logits)
     torch.cuda.synchronize()
     ctx.close()
+
+
+def test_relu_by_height_equals_the_recursion():
+    """ChebyshevEvaluator.batched: every node of one height at one level (batched products) computes the same
+    polynomial as the depth-first recursion, at the same level and scale"""
+    relu = cnn.ApproxReLU()
+    ev = _sim(levels=16, bits=46)
+    vals = np.random.default_rng(8).uniform(-1, 1, 1000)
+    ct = ev.encrypt(ev.encode(vals.astype(np.complex128), 2.0 ** 46, 1, 1 << LOGN))
+    relu.batched, relu.parallel = False, False
+    a = relu.evaluate(ev, ct)
+    relu.batched = True
+    b = relu.evaluate(ev, ct)
+    assert a.level == b.level and abs(a.scale / b.scale - 1) < 1e-12
+    assert np.abs(ev.decrypt_decode(a, 1 << LOGN) - ev.decrypt_decode(b, 1 << LOGN)).max() < 1e-9
