@@ -22,7 +22,7 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", *os.environ.get("PHA_EXTRA_DEFINES", "").split(),
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
     if verbose:
         print(" ".join(cmd))

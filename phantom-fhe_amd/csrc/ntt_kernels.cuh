@@ -299,13 +299,55 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, uint64_t *base, con
 #endif
 }
 
+#ifndef PHA_COL_PAIR
+#define PHA_COL_PAIR 0      // experiment: one workgroup transforms two adjacent column tiles, the second one's loads issued
+#endif                      // before the first one is computed (576 workgroups in one resident round, 32 loads in flight per
+                            // lane).  Measured at configs[1]: 20.2 us against 18.2 us — fewer, fatter waves hide less.
+#if PHA_COL_PAIR
+// two adjacent tiles of one limb: all 32 loads of a lane are in flight before the first butterfly
+template <int S1, int RA, class F>
+__device__ __forceinline__ void fntt_col_body2(uint64_t *lds, uint64_t *base, const tw_t *tw_raw, uint32_t n2, uint32_t root,
+                                               const F &f) {
+    constexpr int RB = S1 - RA, C = kTile >> S1;
+    using TW = typename F::twl;
+    const TW *tw = reinterpret_cast<const TW *>(tw_raw);
+    const uint32_t t = threadIdx.x, c = t % C, r = t / C;
+    typename F::elem x0[1 << RA], x1[1 << RA];
+#pragma unroll
+    for (int j = 0; j < (1 << RA); j++) x0[j] = f.from_u64(base[static_cast<size_t>((j << RB) | r) * n2 + c]);
+#pragma unroll
+    for (int j = 0; j < (1 << RA); j++) x1[j] = f.from_u64(base[static_cast<size_t>((j << RB) | r) * n2 + C + c]);
+    auto finish = [&](typename F::elem (&x)[1 << RA], uint32_t col0) {
+        ct_radix<RA, 0>(x, CanonTw<TW>{tw, root}, f);
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) lds[lds_col<C, RB>((j << RB) | r, c)] = F::raw(x[j]);
+        __syncthreads();
+        typename F::elem y[1 << RB];
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) y[j] = F::unraw(lds[lds_col<C, RB>((r << RB) | j, c)]);
+        ct_radix<RB, RA>(y, CanonTw<TW>{tw, (root << RA) + r}, f);
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) st_stream(&base[static_cast<size_t>((r << RB) | j) * n2 + col0 + c], F::raw(y[j]));
+    };
+    finish(x0, 0);
+    __syncthreads();
+    finish(x1, C);
+}
+#endif
+
 template <int S1, int RA, bool NARROW>
 __global__ PHA_NTT_BOUNDS void fntt_col_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm) {
     constexpr int C = kTile >> S1;
     __shared__ uint64_t lds[kLdsWords];
     const uint32_t n = 1u << T.log_n, tiles = n >> kTileLog;
     uint32_t poly, tile;
-    decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
+    constexpr bool PAIR = PHA_COL_PAIR && RA == 4 && S1 - RA == 4;
+    if (PAIR) {
+        decode_block(blockIdx.x, lm.polys, lm.active * (tiles / 2), poly, tile);
+        tile *= 2;
+    } else {
+        decode_block(blockIdx.x, lm.polys, lm.active * tiles, poly, tile);
+    }
     const uint32_t li = tile / tiles, ti = tile % tiles;
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, li, twr, tidx)) return;
@@ -313,10 +355,21 @@ __global__ PHA_NTT_BOUNDS void fntt_col_kernel(uint64_t *data, size_t poly_strid
     uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + st.offset + st.tile * C;
     const DModulus mod = T.mod[tidx];
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
+#if PHA_COL_PAIR
+    if constexpr (PAIR) {
+        if (use_fp64(T, mod))
+            fntt_col_body2<S1, RA>(lds, base, tw, st.n2, st.root, FpField(mod));
+        else
+            fntt_col_body2<S1, RA>(lds, base, tw, st.n2, st.root, IntField<NARROW>(mod));
+        return;
+    }
+#endif
+#if 1
     if (use_fp64(T, mod))
         fntt_col_body<S1, RA>(lds, base, tw, st.n2, st.root, FpField(mod));
     else
         fntt_col_body<S1, RA>(lds, base, tw, st.n2, st.root, IntField<NARROW>(mod));
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

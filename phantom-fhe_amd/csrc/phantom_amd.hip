@@ -275,6 +275,7 @@ int make_range(const pha_context *ctx, size_t count, size_t start, size_t size_Q
 
 template <int S, int RA>
 void launch_fcol(bool narrow, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, const NttTables &T, const LimbMap &lm) {
+    if (PHA_COL_PAIR && RA == 4 && S - RA == 4) grid.x /= 2;  // one workgroup per pair of adjacent tiles
     if (narrow)
         hipLaunchKernelGGL((fntt_col_kernel<S, RA, true>), grid, dim3(kThreads), 0, st, data, ps, T, lm);
     else
