@@ -58,6 +58,7 @@ def parse(argv=None):
     ap.add_argument("--delta-bits", type=int, default=42)
     ap.add_argument("--evalmod-bits", type=int, default=56)
     ap.add_argument("--image-seed", type=int, default=0)
+    ap.add_argument("--params", default="", help="npz of parameters for --layers (tools/make_resnet20_fixture.py <layers> <out.npz>)")
     ap.add_argument("--no-slim", action="store_true", help="SlotToCoeff after EvalMod (the usual order) instead of before the modulus raise")
     ap.add_argument("--graph", action="store_true", help="also capture the inference in one HIP graph and time its replay")
     ap.add_argument("--streams", type=int, default=1, help="2: a second, independent inference on a sibling (context, stream) pair, both as HIP graphs (throughput)")
@@ -68,10 +69,12 @@ def parse(argv=None):
 def run(args):
     t0 = time.perf_counter()
     ctx, ev, boot, relu, mods = build(args)
-    if args.layers == 20:
+    if args.params:
+        params = cnn.load_parameters_npz(args.params)
+    elif args.layers == 20:
         params = cnn.load_parameters_npz(os.path.join(ROOT, "tests", "golden", "resnet20_cifar10.npz"))
     else:
-        params = cnn_ref.synthetic_parameters({8: 0, 14: 1, 32: 4}[args.layers], seed=1)
+        params = cnn_ref.synthetic_parameters({8: 0, 14: 1, 32: 4, 44: 6, 56: 8, 110: 17}[args.layers], seed=1)
     net = cnn.ResNetCifar10(ev, params, layer_num=args.layers, B=40.0, relu=relu, bootstrappers=boot)
     image = smooth_image(args.image_seed)
     level = net.input_level()
@@ -110,7 +113,7 @@ def run(args):
            "repeat_logit_diff": float(np.abs(again - logits).max()),
            "rotation_keys": len(ev.galois), "rotation_key_bytes": key_bytes, "encoded_constants": sum(1 for v in net.cache.store.values() if v is not None and v is not True),
            "setup_s": round(setup_s, 2), "first_inference_s": round(first_s, 2), "n_gpus": 1,
-           "data": "reference's pretrained ResNet-20 parameters, synthetic image" if args.layers == 20 else "synthetic parameters and image"}
+           "data": ("reference's pretrained ResNet-%d parameters, synthetic image" % args.layers) if (args.layers == 20 or args.params) else "synthetic parameters and image"}
     if args.graph:
         t0 = time.perf_counter()
         run = net.capture(x)
