@@ -67,6 +67,15 @@ def parse(argv=None):
 
 
 def run(args):
+    # one process per GPU under torch.distributed.run: every rank runs its own image (replicas: the network does not
+    # shard, SURVEY.md 8e "one image per GPU"); no data-path collective, the timing is barrier + max over ranks
+    rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        args.image_seed += rank
     t0 = time.perf_counter()
     ctx, ev, boot, relu, mods = build(args)
     if args.params:
@@ -96,10 +105,19 @@ def run(args):
     times = []
     for _ in range(args.reps):
         torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
         t0 = time.perf_counter()
         out = net(x)
         torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        times.append(dt)
     again = net.decrypt_logits(out)
     key_bytes = sum(k.numel() * 8 for k in ev.galois.values()) if ev.galois and hasattr(next(iter(ev.galois.values())), "numel") else None
     res = {"metric": "encrypted ResNet-%d CIFAR-10 inference ms" % args.layers, "value": 1e3 * min(times), "unit": "ms", "log_n": args.log_n,
@@ -112,7 +130,7 @@ def run(args):
            "max_activation_over_B": float(max(np.abs(v).max() for v in want_seen.values()) / B),
            "repeat_logit_diff": float(np.abs(again - logits).max()),
            "rotation_keys": len(ev.galois), "rotation_key_bytes": key_bytes, "encoded_constants": sum(1 for v in net.cache.store.values() if v is not None and v is not True),
-           "setup_s": round(setup_s, 2), "first_inference_s": round(first_s, 2), "n_gpus": 1,
+           "setup_s": round(setup_s, 2), "first_inference_s": round(first_s, 2), "n_gpus": world, "images_per_s": world / min(times), "scaling": "weak",
            "data": ("reference's pretrained ResNet-%d parameters, synthetic image" % args.layers) if (args.layers == 20 or args.params) else "synthetic parameters and image"}
     if args.graph:
         t0 = time.perf_counter()
@@ -212,8 +230,17 @@ def run(args):
         net(x)
         res["method_ms"] = {k: [round(v, 2), calls[k]] for k, v in sorted(inner.items(), key=lambda kv: -kv[1])}
     ctx.close()
+    if dist is not None:
+        ok = torch.tensor([1.0 if res["argmax"] == res["argmax_plain"] and res["max_logit_error_vs_plain_same_relu"] < 1e-2 else 0.0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        res["all_ranks_correct"] = bool(ok.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    res["rank"] = rank
     return res
 
 
 if __name__ == "__main__":
-    print(json.dumps(run(parse())), flush=True)
+    result = run(parse())
+    if result["rank"] == 0:
+        print(json.dumps(result), flush=True)
