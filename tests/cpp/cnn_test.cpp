@@ -112,10 +112,13 @@ static CnnParameters synthetic_parameters(size_t end_num, uint64_t seed) {
     return p;
 }
 
+// fast chain (default): 38-bit messages, 48-bit EvalMod primes, EIGHT 50-bit special primes (dnum 4, every prime on the FP64
+// transform path, log2 QP = 1750 at N = 2^16); precise: 42 / 56 bits, four 60-bit special primes (dnum 8, log2 QP = 1758)
 static int run(const char *name, long logN, int image_hw, size_t end_num, CnnParameters params, double B, size_t hamming_weight, long boundary_K,
-               long scale_factor, int reps) {
-    const int logp = 42, logq0 = 52, log_evalmod = 56, log_c2s = 50, c2s_levels = 3, s2c_levels = 2;
-    const size_t special = 4;
+               long scale_factor, int reps, bool precise = false) {
+    const int logp = precise ? 42 : 38, logq0 = logp + 10, log_evalmod = precise ? 56 : 48, log_c2s = logp + 8, c2s_levels = 3, s2c_levels = 2;
+    const size_t special = precise ? 4 : 8;
+    const int special_bits = precise ? 60 : 50;
     ApproxReLU relu;
     const int cnn_levels = relu.depth + 2, evalmod_levels = (5 + 1) + static_cast<int>(scale_factor);
     std::vector<int> bits{logq0};
@@ -124,7 +127,7 @@ static int run(const char *name, long logN, int image_hw, size_t end_num, CnnPar
     for (int i = 0; i < c2s_levels; i++) bits.push_back(log_c2s);
     while (bits.size() % special) bits.insert(bits.begin() + 1, logp);
     const size_t q_limbs = bits.size();
-    for (size_t i = 0; i < special; i++) bits.push_back(60);
+    for (size_t i = 0; i < special; i++) bits.push_back(special_bits);
 
     EncryptionParameters parms;
     const size_t N = size_t(1) << logN;
@@ -197,8 +200,10 @@ static int run(const char *name, long logN, int image_hw, size_t end_num, CnnPar
 
 int main(int argc, char **argv) {
     try {
-        if (argc > 2 && std::string(argv[1]) == "bench") return run("resnet20_2^16", 16, 32, 2, import_parameters_cifar10(argv[2], 2), 40.0, 192, 25, 4, 2);
-        return run("resnet8_2^13", 13, 8, 0, synthetic_parameters(0, 3), 16.0, 32, 12, 3, 1);
+        if (argc > 2 && std::string(argv[1]) == "bench")
+            return run("resnet20_2^16", 16, 32, 2, import_parameters_cifar10(argv[2], 2), 40.0, 192, 25, 4, 2, argc > 3 && std::string(argv[3]) == "precise");
+        const int rc = run("resnet8_2^13", 13, 8, 0, synthetic_parameters(0, 3), 16.0, 32, 12, 3, 1);
+        return rc ? rc : run("resnet8_2^13_precise", 13, 8, 0, synthetic_parameters(0, 3), 16.0, 32, 12, 3, 1, true);
     } catch (const std::exception &e) {
         fprintf(stderr, "FAILED: %s\n", e.what());
         return 1;

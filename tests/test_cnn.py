@@ -180,19 +180,19 @@ def test_parameter_files(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("slim", [True, False])
-def test_resnet8_with_bootstrapping_on_the_gpu(slim):
+@pytest.mark.parametrize("slim,d,e,alpha,special", [(True, 42, 56, 4, 60), (False, 42, 56, 4, 60), (True, 38, 48, 8, 50)])
+def test_resnet8_with_bootstrapping_on_the_gpu(slim, d, e, alpha, special):
     """N = 2^13, 8 x 8 images: three residual blocks, six bootstrappings (1024, 512 and 256 sparse slots), every
     ciphertext operation through the C ABI; logits against the plain network with the same ReLU polynomial."""
     import torch
     from phantom_fhe_amd.bootstrap import Bootstrapper
     from phantom_fhe_amd.ckks import GpuEvaluator
-    log_n, d, e, g, alpha = 13, 42, 56, 3, 4
+    log_n, g = 13, 3
     relu = cnn.default_relu()
     q_bits = [d + 10] + [d] * (relu.depth + 2) + [d] * g + [e] * 9 + [d + 8] * g
     assert len(q_bits) % alpha == 0
     n = 1 << log_n
-    mods = pha.coeff_modulus_create(n, q_bits + [60] * alpha)
+    mods = pha.coeff_modulus_create(n, q_bits + [special] * alpha)     # 50-bit special primes: every limb on the FP64 path, dnum 4
     ctx = pha.PhantomContext(log_n, mods, alpha)
     sk = ctx.gen_secretkey(21, hamming_weight=32)
     ev = GpuEvaluator(pha, ctx, sk, n // 2)

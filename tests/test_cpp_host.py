@@ -47,9 +47,14 @@ def test_cpp_resnet_with_bootstrapping(gpu):
     assert os.path.exists(exe), "tests/cpp/cnn_test not built (run __graft_entry__.build())"
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["resnet8_2^13"]
-    assert res["bootstrappings"] == 6 and res["relu_levels"] == 14 and res["relu_alpha"] > 13.0
-    assert res["max_logit_error_vs_plain_same_relu"] < 1e-3 and res["argmax"] == res["argmax_plain"]
+    lines = {}
+    for l in out.stdout.splitlines():
+        if l.startswith("{"):
+            lines.update(json.loads(l))
+    for key, special in (("resnet8_2^13", 8), ("resnet8_2^13_precise", 4)):     # dnum 4 with 50-bit special primes, dnum 8 with 60-bit ones
+        res = lines[key]
+        assert res["bootstrappings"] == 6 and res["relu_levels"] == 14 and res["relu_alpha"] > 13.0 and res["special_primes"] == special
+        assert res["max_logit_error_vs_plain_same_relu"] < 1e-3 and res["argmax"] == res["argmax_plain"]
 
 
 @pytest.mark.gpu
