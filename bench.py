@@ -187,36 +187,38 @@ def secondary_metrics(torch, pha):
     ctx.close()
     del ev, bs, ct, out
 
-    # full slots (BASELINE configs[4]'s primitive): 32768 slots, messages at 2^46, EvalMod at 2^58, four levels per
-    # linear transform, 9 levels left after the bootstrap; log2(QP) = 1714, inside the 1761-bit bound for N = 2^16
-    d, e, slots, groups = 46, 58, N // 2, 4
-    q_bits = [d + 10] + [d] * 9 + [d] * groups + [e] * 10 + [60] * groups
-    while len(q_bits) % alpha:
-        q_bits.insert(1, d)
-    mods = pha.coeff_modulus_create(N, q_bits + [60] * alpha)
-    ctx = pha.PhantomContext(LOG_N, mods, alpha)
-    ev = GpuEvaluator(pha, ctx, ctx.gen_secretkey(21, hamming_weight=192), slots)
-    # slim order: SlotToCoeff runs first, on the last `groups` levels, so the ciphertext enters that many levels early
-    bs = Bootstrapper(ev, K=25, r=4, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d, transform="fft", c2s_groups=groups,
-                      s2c_groups=groups, slim=True)
-    msg = np.random.default_rng(4).uniform(-1, 1, slots) + 1j * np.random.default_rng(5).uniform(-1, 1, slots)
-    ct = ev.encrypt(ev.encode(msg, 2.0 ** d, ev.bottom - bs.pre_levels))
-    out = bs.bootstrap(ct)
-    res["bootstrap_full_slots_max_abs_error"] = float(np.abs(ev.decrypt_decode(out) - msg).max())
-    times = []
-    for _ in range(3):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        bs.bootstrap(ct)
-        torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
-    res["bootstrap_full_slots_ms"] = 1e3 * min(times)
-    res["bootstrap_full_slots_config"] = (f"N=2^16, {slots} slots, {len(q_bits)} Q limbs + {alpha} special primes, h=192, message scale "
-                                          f"2^{d}, EvalMod at 2^{e}, SlotToCoeff first (slim order), {ev.limbs(out.level) - 1 - bs.pre_levels} levels left between "
-                                          f"bootstrappings, log2(QP) = "
-                                          f"{float(sum(np.log2(np.array(mods, dtype=np.float64)))):.0f}")
-    ctx.close()
-    del ev, bs, ct, out
+    # full slots (BASELINE configs[4]'s primitive): 32768 slots, four levels per linear transform, slim order (SlotToCoeff first,
+    # on the last levels), 9 levels left between bootstrappings; both chains inside the 1761-bit bound for N = 2^16:
+    #   precise: messages 2^46, EvalMod 2^58, 28 + 4 limbs with 60-bit special primes (dnum 7), log2(QP) = 1714
+    #   dnum 4 : messages 2^40, EvalMod 2^48, 28 + 7 limbs, every prime at most 50 bits (FP64 transform path), log2(QP) = 1592
+    for tag, d, e, alpha, special_bits in (("", 46, 58, 4, 60), ("_dnum4", 40, 48, 7, 50)):
+        slots, groups = N // 2, 4
+        q_bits = [d + 10] + [d] * 9 + [d] * groups + [e] * 10 + [min(60, d + 8) if not tag else e] * groups
+        while len(q_bits) % alpha:
+            q_bits.insert(1, d)
+        mods = pha.coeff_modulus_create(N, q_bits + [special_bits] * alpha)
+        ctx = pha.PhantomContext(LOG_N, mods, alpha)
+        ev = GpuEvaluator(pha, ctx, ctx.gen_secretkey(21, hamming_weight=192), slots)
+        bs = Bootstrapper(ev, K=25, r=4, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d, transform="fft", c2s_groups=groups,
+                          s2c_groups=groups, slim=True)
+        msg = np.random.default_rng(4).uniform(-1, 1, slots) + 1j * np.random.default_rng(5).uniform(-1, 1, slots)
+        ct = ev.encrypt(ev.encode(msg, 2.0 ** d, ev.bottom - bs.pre_levels))
+        out = bs.bootstrap(ct)
+        res[f"bootstrap_full_slots{tag}_max_abs_error"] = float(np.abs(ev.decrypt_decode(out) - msg).max())
+        times = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            bs.bootstrap(ct)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        res[f"bootstrap_full_slots{tag}_ms"] = 1e3 * min(times)
+        res[f"bootstrap_full_slots{tag}_config"] = (f"N=2^16, {slots} slots, {len(q_bits)} Q limbs + {alpha} special primes of {special_bits} bits, h=192, "
+                                                    f"message scale 2^{d}, EvalMod at 2^{e}, SlotToCoeff first (slim order), "
+                                                    f"{ev.limbs(out.level) - 1 - bs.pre_levels} levels left between bootstrappings, log2(QP) = "
+                                                    f"{float(sum(np.log2(np.array(mods, dtype=np.float64)))):.0f}")
+        ctx.close()
+        del ev, bs, ct, out
 
     # BASELINE configs[4]: bootstrapping driving the ResNet-20 / CIFAR-10 example (tools/bench_resnet20.py: the
     # reference's pretrained parameters, a synthetic image, logits checked against the plain network)

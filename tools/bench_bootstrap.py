@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--delta-bits", type=int, default=50, help="working scale; q0 has 10 bits more")
     ap.add_argument("--transform", choices=("dense", "fft"), default="dense")
     ap.add_argument("--groups", type=int, default=3, help="levels of each FFT-factored transform")
+    ap.add_argument("--special-bits", type=int, default=60, help="size of the special primes (below 2^50: FP64 transform path)")
+    ap.add_argument("--c2s-bits", type=int, default=0, help="CoeffToSlot primes (default: min(60, delta-bits + 8))")
     ap.add_argument("--slim", action="store_true", help="SlotToCoeff first, on the last levels (needs --transform fft)")
     ap.add_argument("--s2c-groups", type=int, default=0, help="levels of SlotToCoeff (default: --groups)")
     ap.add_argument("--evalmod-bits", type=int, default=0, help="EvalMod working scale / primes (default: delta-bits)")
@@ -34,12 +36,12 @@ def main():
     if args.transform == "fft":
         g = min(args.groups, args.slots.bit_length() - 1)
         g2 = min(args.s2c_groups or args.groups, args.slots.bit_length() - 1)
-        q_bits = [d + 10] + [d] * args.extra_levels + [d] * g2 + evalmod + [min(60, d + 8)] * g
+        q_bits = [d + 10] + [d] * args.extra_levels + [d] * g2 + evalmod + [args.c2s_bits or min(60, d + 8)] * g
     else:
         q_bits = [d + 10] + [d] * args.extra_levels + [d] + evalmod + [d, min(60, d + 18)]
     while len(q_bits) % args.alpha:
         q_bits.insert(1, d)
-    mods = pha.coeff_modulus_create(n, q_bits + [60] * args.alpha)
+    mods = pha.coeff_modulus_create(n, q_bits + [args.special_bits] * args.alpha)
     ctx = pha.PhantomContext(args.log_n, mods, args.alpha)
     sk = ctx.gen_secretkey(21, hamming_weight=192 if args.log_n >= 15 else 32)
     ev = GpuEvaluator(pha, ctx, sk, args.slots)
