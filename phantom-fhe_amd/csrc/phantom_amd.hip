@@ -141,8 +141,9 @@ struct pha_context {
     DevBuf<uint64_t> workspace;
     DevBuf<uint64_t> d_bigP_mod_q;  // key level, [size_Q] (key generation)
     // helper stream for the independent giant-step chains of pha_linear_transform_double_hoisted
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+    static constexpr int kAuxStreams = 3;                // helper streams of the double-hoisted transform's giant chains
+    hipStream_t aux_stream[kAuxStreams] = {nullptr, nullptr, nullptr};
+    hipEvent_t aux_fork = nullptr, aux_join[kAuxStreams] = {nullptr, nullptr, nullptr};
     // CKKS encoder: rotation group 5^j mod 2N and per-level CRT composition tables
     struct EncoderLevel {
         DevBuf<uint64_t> big_q, half_q, qhat, inv_qhat;
@@ -1133,8 +1134,10 @@ void pha_context_destroy(pha_context *ctx) {
     if (!ctx) return;
     (void)hipDeviceSynchronize();
     if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
-    if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
-    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    for (int c = 0; c < pha_context::kAuxStreams; c++) {
+        if (ctx->aux_join[c]) (void)hipEventDestroy(ctx->aux_join[c]);
+        if (ctx->aux_stream[c]) (void)hipStreamDestroy(ctx->aux_stream[c]);
+    }
     delete ctx;
 }
 
@@ -1825,31 +1828,36 @@ int pha_linear_transform_double_hoisted(pha_context *ctx, size_t chain_index, co
     // launches: with two or more of them, every other chain runs on the context's helper stream with its own buffers.
     size_t rotating = 0;
     for (size_t g = 0; g < n_giant; g++) rotating += giant_elts_host[g] != 1;
-    static const bool two_streams_ok = [] {
+    // (PHA_GIANT_STREAMS = 1 .. 4 sets the number of chains, default 2, 1 = all on the caller's stream; measured on the
+    // CNN's bootstrappings: 2 chains 1-2 % over 1, 4 chains the same as 2)
+    static const size_t max_chains = [] {
         const char *e = getenv("PHA_GIANT_STREAMS");
-        return !(e && e[0] == '1');
+        const int v = e ? atoi(e) : 2;
+        return static_cast<size_t>(std::min(1 + pha_context::kAuxStreams, std::max(1, v)));
     }();
-    const bool two = two_streams_ok && rotating >= 2;
-    if (two && !ctx->aux_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming));
-    }
+    const size_t n_chains = std::max<size_t>(1, std::min(max_chains, rotating));
+    const bool two = n_chains >= 2;
+    if (two && !ctx->aux_fork) HIP_TRY(hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
+    for (size_t c = 1; c < n_chains; c++)
+        if (!ctx->aux_stream[c - 1]) {
+            HIP_TRY(hipStreamCreateWithFlags(&ctx->aux_stream[c - 1], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->aux_join[c - 1], hipEventDisableTiming));
+        }
     const size_t chain_words = ((lt->beta + 6) * size_QlP + 4 * size_Ql) * n;   // t_mod_up | cx | acc | total | scratch | u
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, (two ? 2 : 1) * chain_words + 2 * n_baby * size_QlP * n, &ws));
+    PHA_TRY(ensure_workspace(ctx, n_chains * chain_words + 2 * n_baby * size_QlP * n, &ws));
     struct Chain {
         hipStream_t st;
         uint64_t *t_mod_up, *cx, *acc, *total, *scratch, *u;
         bool first;
-    } chains[2];
-    for (int c = 0; c < 2; c++) {
+    } chains[1 + pha_context::kAuxStreams];
+    for (size_t c = 0; c < n_chains; c++) {
         uint64_t *base = ws + c * chain_words;
-        chains[c] = Chain{c ? ctx->aux_stream : st, base, base + lt->beta * size_QlP * n, base + (lt->beta + 2) * size_QlP * n,
+        chains[c] = Chain{c ? ctx->aux_stream[c - 1] : st, base, base + lt->beta * size_QlP * n, base + (lt->beta + 2) * size_QlP * n,
                           base + (lt->beta + 4) * size_QlP * n, base + (lt->beta + 6) * size_QlP * n,
                           base + (lt->beta + 6) * size_QlP * n + 2 * size_Ql * n, true};
     }
-    uint64_t *rot = ws + (two ? 2 : 1) * chain_words;
+    uint64_t *rot = ws + n_chains * chain_words;
     const uint32_t n32 = static_cast<uint32_t>(n), ql = static_cast<uint32_t>(size_Ql), qlp = static_cast<uint32_t>(size_QlP),
                    sq = static_cast<uint32_t>(ctx->size_Q);
     const dim3 grid_qp(qlp * (n32 / 512), 2), grid_qp1(qlp * (n32 / 512), 1);
@@ -1881,9 +1889,9 @@ int pha_linear_transform_double_hoisted(pha_context *ctx, size_t chain_index, co
     if (any_rot) PHA_TRY(do_modup(ctx, lt, main_chain.t_mod_up, ct + size_Ql * n, main_chain.scratch, st));
     for (size_t b = 0; b < n_baby; b++)
         PHA_TRY(rotate_qp(main_chain, rot + 2 * b * size_QlP * n, ct, baby_elts_host[b], baby_evks_host[b]));
-    if (two) {  // the helper stream starts once the baby rotations exist
+    if (two) {  // the helper streams start once the baby rotations exist
         HIP_TRY(hipEventRecord(ctx->aux_fork, st));
-        HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
+        for (size_t c = 1; c < n_chains; c++) HIP_TRY(hipStreamWaitEvent(ctx->aux_stream[c - 1], ctx->aux_fork, 0));
     }
     size_t rot_index = 0;
     for (size_t g = 0; g < n_giant; g++) {
@@ -1896,7 +1904,7 @@ int pha_linear_transform_double_hoisted(pha_context *ctx, size_t chain_index, co
         }
         if (!terms.count) continue;
         const bool rotates = giant_elts_host[g] != 1;
-        Chain &ch = chains[(two && rotates) ? (rot_index++ & 1) : 0];
+        Chain &ch = chains[(two && rotates) ? (rot_index++ % n_chains) : 0];
         hipLaunchKernelGGL(multi_mac_qp_kernel, dim3(qlp * (n32 / 512)), dim3(256), 0, ch.st, ch.acc, terms, mod, n32, ql, qlp, sq);
         PHA_TRY(check_launch("multi_mac_qp"));
         const uint64_t *add = ch.acc;
@@ -1908,10 +1916,10 @@ int pha_linear_transform_double_hoisted(pha_context *ctx, size_t chain_index, co
         }
         PHA_TRY(accumulate(ch, add));
     }
-    if (two) {  // join: the helper chain's partial sum goes into the main one
-        HIP_TRY(hipEventRecord(ctx->aux_join, ctx->aux_stream));
-        HIP_TRY(hipStreamWaitEvent(st, ctx->aux_join, 0));
-        if (!chains[1].first) PHA_TRY(accumulate(main_chain, chains[1].total));
+    for (size_t c = 1; c < n_chains; c++) {  // join: the helper chains' partial sums go into the main one
+        HIP_TRY(hipEventRecord(ctx->aux_join[c - 1], ctx->aux_stream[c - 1]));
+        HIP_TRY(hipStreamWaitEvent(st, ctx->aux_join[c - 1], 0));
+        if (!chains[c].first) PHA_TRY(accumulate(main_chain, chains[c].total));
     }
     if (main_chain.first) return fail(PHA_ERR_INVALID_ARGUMENT, "the transform has no plaintext");
     return do_moddown(ctx, lt, out, main_chain.total, main_chain.scratch, nullptr, 2, st);
