@@ -62,6 +62,7 @@ SIGNATURES = {
     "pha_ntt_forward_batched": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "pha_ntt_backward_batched": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "pha_ntt_launch_phase": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _int, _int, _vp]),
+    "pha_ntt_block_placement": (_int, [_vp, _int]),
     "pha_modup": (_int, [_vp, _sz, _vp, _vp, _vp]),
     "pha_key_switch_inner_prod": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _vp]),
     "pha_moddown_from_ntt": (_int, [_vp, _sz, _vp, _vp, _vp]),
@@ -311,6 +312,9 @@ class PhantomContext:
     def ntt_launch_phase(self, inout, polys, poly_stride_limbs, count, start, inverse, phase):
         _check(lib().pha_ntt_launch_phase(self._h, _ptr(inout), polys, poly_stride_limbs, count, start, int(inverse),
                                           int(phase), _stream()))
+
+    def ntt_block_placement(self, limb_to_xcd):
+        _check(lib().pha_ntt_block_placement(self._h, int(limb_to_xcd)))
 
     # DRNSTool ---------------------------------------------------------------------------------
     def modup(self, chain_index, dst, cks):

@@ -152,6 +152,9 @@ struct pha_context {
     DevBuf<uint32_t> d_rot_group;
     std::map<size_t, std::unique_ptr<EncoderLevel>> enc_levels;
 
+    int num_cus = 0;
+    uint32_t xcd_map = 1;     // limb-to-XCD block placement of the NTT kernels (PHA_XCD_MAP=0: tile-interleaved, round 1)
+
     NttTables fwd_tables() const {
         return NttTables{d_mod.p, d_tw.p, d_twD.p, d_n_inv.p, d_n_inv_shoup.p, static_cast<uint32_t>(log_n), twD_stride,
                          fp64 ? 1u : 0u, static_cast<uint32_t>(plan.split)};
@@ -276,7 +279,6 @@ int make_range(const pha_context *ctx, size_t count, size_t start, size_t size_Q
 
 template <int S, int RA>
 void launch_fcol(bool narrow, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, const NttTables &T, const LimbMap &lm) {
-    if (PHA_COL_PAIR && RA == 4 && S - RA == 4) grid.x /= 2;  // one workgroup per pair of adjacent tiles
     if (narrow)
         hipLaunchKernelGGL((fntt_col_kernel<S, RA, true>), grid, dim3(kThreads), 0, st, data, ps, T, lm);
     else
@@ -315,7 +317,7 @@ void launch_icol(int epi, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, 
     if (T.split) {
         // subtrees only (instantiated for the N = 2^17 plan); N^-1 and the epilogue follow in split_inv_kernel
         hipLaunchKernelGGL((intt_col_kernel<8, 4, EPI_NONE, true>), grid, dim3(kThreads), 0, st, data, ps, T, lm, ep);
-        const dim3 g2(grid.x >> (13 - kTileLog));
+        const dim3 g2(lm.xcd_map ? xcd_grid_blocks(lm.active, lm.polys, (1u << T.log_n) >> 13) : grid.x >> (13 - kTileLog));
         if (epi == EPI_SCALE)
             hipLaunchKernelGGL((split_inv_kernel<EPI_SCALE>), g2, dim3(256), 0, st, data, ps, T, lm, ep);
         else
@@ -335,15 +337,20 @@ void launch_icol(int epi, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, 
         default: CALL8; break;                 \
     }
 
+uint32_t ntt_grid_blocks(const pha_context *ctx, uint32_t active, size_t polys, size_t tiles) {
+    const uint32_t p = static_cast<uint32_t>(polys), t = static_cast<uint32_t>(tiles);
+    return ctx->xcd_map ? xcd_grid_blocks(active, p, t) : active * p * t;
+}
 int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stride, const NttRange &r, int epi,
                 const Epilogue &ep, hipStream_t st, int phases = 3) {
     if (!r.active || !polys) return PHA_OK;
-    const dim3 grid(r.active * static_cast<uint32_t>(ctx->n >> kTileLog) * static_cast<uint32_t>(polys));
     const NttTables T = ctx->fwd_tables();
     NttRange rr = r;
     rr.lm.polys = static_cast<uint32_t>(polys);
+    rr.lm.xcd_map = ctx->xcd_map;
+    const dim3 grid(ntt_grid_blocks(ctx, r.active, polys, ctx->n >> kTileLog));
     if ((phases & 1) && T.split)
-        hipLaunchKernelGGL(split_fwd_kernel, dim3(r.active * static_cast<uint32_t>(ctx->n >> 13) * static_cast<uint32_t>(polys)), dim3(256), 0, st,
+        hipLaunchKernelGGL(split_fwd_kernel, dim3(ntt_grid_blocks(ctx, r.active, polys, ctx->n >> 13)), dim3(256), 0, st,
                            data, poly_stride, T, rr.lm);
     if (phases & 1)
     DISPATCH_S(ctx->plan.s1, 0, (launch_fcol<6, 3>(ctx->narrow, grid, st, data, poly_stride, T, rr.lm)),
@@ -359,10 +366,11 @@ int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stri
 int ntt_backward(pha_context *ctx, uint64_t *out, const uint64_t *in, size_t polys, size_t poly_stride,
                  const NttRange &r, int epi, const Epilogue &ep, hipStream_t st, int phases = 3) {
     if (!r.active || !polys) return PHA_OK;
-    const dim3 grid(r.active * static_cast<uint32_t>(ctx->n >> kTileLog) * static_cast<uint32_t>(polys));
     const NttTables T = ctx->inv_tables();
     NttRange rr = r;
     rr.lm.polys = static_cast<uint32_t>(polys);
+    rr.lm.xcd_map = ctx->xcd_map;
+    const dim3 grid(ntt_grid_blocks(ctx, r.active, polys, ctx->n >> kTileLog));
     if (phases & 2)
     DISPATCH_S(ctx->plan.s2, 0, (launch_irow<6, 3>(grid, st, out, in, poly_stride, T, rr.lm)),
                (launch_irow<7, 4>(grid, st, out, in, poly_stride, T, rr.lm)),
@@ -1115,6 +1123,17 @@ int pha_context_create(int log_n, const uint64_t *moduli_QP, size_t size_QP, siz
     ctx->moduli.assign(moduli_QP, moduli_QP + size_QP);
     const char *no_fp = getenv("PHA_DISABLE_FP64");
     ctx->fp64 = !(no_fp && no_fp[0] == '1');
+    {
+        auto env_u = [](const char *name, uint32_t dflt) {
+            const char *e = getenv(name);
+            return e && *e ? static_cast<uint32_t>(atoi(e)) : dflt;
+        };
+        ctx->xcd_map = env_u("PHA_XCD_MAP", 1) ? 1u : 0u;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            ctx->num_cus = prop.multiProcessorCount;
+    }
     ctx->narrow = true;
     for (size_t i = 0; i < size_QP; i++) ctx->narrow = ctx->narrow && (moduli_QP[i] >> 60) == 0;
     ctx->host_tables.resize(size_QP);
@@ -1276,6 +1295,12 @@ int pha_ntt_launch_phase(pha_context *ctx, uint64_t *inout, size_t polys, size_t
         return ntt_backward(ctx, inout, inout, polys, poly_stride_limbs * ctx->n, r, EPI_NONE, Epilogue{},
                             as_stream(stream), mask);
     return ntt_forward(ctx, inout, polys, poly_stride_limbs * ctx->n, r, EPI_NONE, Epilogue{}, as_stream(stream), mask);
+}
+
+int pha_ntt_block_placement(pha_context *ctx, int limb_to_xcd) {
+    REQUIRE_CTX(true);
+    ctx->xcd_map = limb_to_xcd ? 1u : 0u;
+    return PHA_OK;
 }
 
 int pha_modup(pha_context *ctx, size_t chain_index, uint64_t *dst, const uint64_t *cks, pha_stream_t stream) {

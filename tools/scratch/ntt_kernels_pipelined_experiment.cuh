@@ -43,7 +43,12 @@ constexpr int kLdsWords = kTile;
 #define PHA_NTT_BOUNDS __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5)))
 #else
 constexpr int kLdsWords = kTile + 512;
-#define PHA_NTT_BOUNDS __launch_bounds__(kThreads)
+// register budget of the pipelined kernels: three workgroups per CU (168 VGPRs; the next tile's 32 registers of loads
+// in flight put the kernels at 180-238 VGPRs when unconstrained, i.e. two per CU)
+#ifndef PHA_NTT_WAVES
+#define PHA_NTT_WAVES 3
+#endif
+#define PHA_NTT_BOUNDS __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PHA_NTT_WAVES, PHA_NTT_WAVES)))
 #endif
 
 struct LimbMap {
@@ -60,6 +65,7 @@ struct LimbMap {
     uint32_t digit_count;           // > 0 with digit_alpha: buffers are [batch][digit_count] and poly p is digit
                                     // p % digit_count (batched key switch)
     uint32_t xcd_map;               // 1: limb-to-XCD placement of decode_block (default), 0: tile-interleaved placement
+    uint32_t blocks;                // logical blocks of the launch (the grid may be smaller: persistent workgroups)
 };
 
 struct NttTables {
@@ -144,11 +150,10 @@ __device__ __forceinline__ bool resolve_limb(const LimbMap &m, uint32_t poly, ui
 // (round-robin dispatch: observed, not promised -- placement is a speed matter only, never a correctness one).
 //
 // Limb-to-XCD placement (xcd_map = 1): every tile of limb slot li, of every poly, runs on XCD li % 8 -- in BOTH kernels
-// of a transform and in every launch with the same limb window -- so that a kernel reads what a workgroup of the same
-// XCD wrote.  Measured on MI355X (tools/scratch/l2_persist.hip, profiles/r2a_l2_persist.log): a kernel that reads
-// 36 MiB which the previous kernel on the stream has just written takes 4.7 us when each block reads what a block of
-// the same XCD wrote and 17.7 us when another XCD wrote it.  On the transforms themselves the gain shows where a launch
-// is short: 2 x 12 limbs forward 25.0 -> 16.2 us, 2 x 36 limbs 34.8 -> 34.5 us (profiles/r2a_xcd_placement.log).
+// of a transform and in every launch with the same limb window.  Measured on MI355X (tools/scratch/l2_persist.hip,
+// profiles/r2_l2_persist.log): a kernel that reads 36 MiB which the previous kernel on the stream has just written
+// takes 4.7 us when each block reads what a block of the same XCD wrote and 17.7 us when another XCD wrote it; the
+// tile-interleaved placement of round 1 (tile t on XCD t % 8) made 7/8 of every row kernel's reads of that second kind.
 // The limbs beyond a multiple of 8 are dealt to the XCDs unit by unit ((limb, poly) pairs) so that the load stays even
 // (configs[1]: 36 limbs x 2 polys = 4 full rounds + 8 units, 9 units per XCD).  Within an XCD's sequence the polys of a
 // tile are adjacent: they read the same twiddles and the second read hits that XCD's L2.
@@ -297,11 +302,49 @@ __device__ __forceinline__ bool use_fp64(const NttTables &T, const DModulus &mod
 }
 
 // ---------------------------------------------------------------------------------------------
+// Persistent, software-pipelined kernels.  A launch has at most (workgroups per CU) x (CUs) workgroups (a multiple of
+// 8, so that a workgroup's logical blocks b, b + gridDim, ... keep their XCD); each walks its logical blocks and has
+// the 16 words per lane of its NEXT tile in flight while it transforms the current one.  Launched one generation at a
+// time (round 1), every workgroup of the chip loaded, computed and stored in lock-step: 4.5 us of loads with idle
+// VALUs, 5.4 us of butterflies with an idle memory system, 7 us of stores (configs[1]).  With gridDim equal to the
+// number of logical blocks the loop runs once and the kernel is the one-tile-per-workgroup kernel of round 1.
+// ---------------------------------------------------------------------------------------------
+struct TileJob {  // wave-uniform
+    uint32_t poly, ti, twr, tidx;
+};
+// first logical block >= b (stride gridDim) that has work
+__device__ __forceinline__ bool next_job(uint32_t &b, const LimbMap &lm, uint32_t tiles, TileJob &j) {
+    for (; b < lm.blocks; b += gridDim.x) {
+        BlockWork bw;
+        if (!decode_block(b, lm, tiles, bw)) continue;
+        uint32_t twr, tidx;
+        if (!resolve_limb(lm, bw.poly, bw.li, twr, tidx)) continue;
+        j = TileJob{bw.poly, bw.ti, twr, tidx};
+        return true;
+    }
+    return false;
+}
+__device__ __forceinline__ void copy16(uint64_t (&dst)[16], const uint64_t (&src)[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward, column phase: stages m = 1 .. 2^(S1-1)
 // ---------------------------------------------------------------------------------------------
+template <int S1, int RA>
+__device__ __forceinline__ void fntt_col_load(uint64_t (&raw)[16], const uint64_t *base, uint32_t n2) {
+    constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA;
+#pragma unroll
+    for (int g = 0; g < GA; g++) {
+        const uint32_t gid = threadIdx.x + kThreads * g, c = gid % C, r_lo = gid / C;
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) raw[(g << RA) + j] = base[static_cast<size_t>((j << RB) | r_lo) * n2 + c];
+    }
+}
 template <int S1, int RA, class F>
-__device__ __forceinline__ void fntt_col_body(uint64_t *lds, uint64_t *base, const tw_t *tw_raw, uint32_t n2, uint32_t root,
-                                              const F &f) {
+__device__ __forceinline__ void fntt_col_body(uint64_t *lds, const uint64_t (&raw)[16], uint64_t *base, const tw_t *tw_raw,
+                                              uint32_t n2, uint32_t root, const F &f) {
     constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
     using TW = typename F::twl;
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
@@ -312,7 +355,7 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, uint64_t *base, con
         const uint32_t gid = t + kThreads * g, c = gid % C, r_lo = gid / C;
         typename F::elem x[1 << RA];
 #pragma unroll
-        for (int j = 0; j < (1 << RA); j++) x[j] = f.from_u64(base[static_cast<size_t>((j << RB) | r_lo) * n2 + c]);
+        for (int j = 0; j < (1 << RA); j++) x[j] = f.from_u64(raw[(g << RA) + j]);
         ct_radix<RA, 0>(x, CanonTw<TW>{tw, root}, f);
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) lds[lds_col<C, RB>((j << RB) | r_lo, c)] = F::raw(x[j]);
@@ -342,28 +385,52 @@ __global__ PHA_NTT_BOUNDS void fntt_col_kernel(uint64_t *data, size_t poly_strid
     constexpr int C = kTile >> S1;
     __shared__ uint64_t lds[kLdsWords];
     const uint32_t n = 1u << T.log_n, tiles = n >> kTileLog;
-    BlockWork bw;
-    if (!decode_block(blockIdx.x, lm, tiles, bw)) return;
-    const uint32_t poly = bw.poly, ti = bw.ti;
-    uint32_t twr, tidx;
-    if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
-    const SubTree st = sub_tree<S1>(T, ti);
-    uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + st.offset + st.tile * C;
-    const DModulus mod = T.mod[tidx];
-    const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
-    if (use_fp64(T, mod))
-        fntt_col_body<S1, RA>(lds, base, tw, st.n2, st.root, FpField(mod));
-    else
-        fntt_col_body<S1, RA>(lds, base, tw, st.n2, st.root, IntField<NARROW>(mod));
+    auto tile_base = [&](const TileJob &j, SubTree &st) {
+        st = sub_tree<S1>(T, j.ti);
+        return data + j.poly * poly_stride + static_cast<size_t>(j.twr) * n + st.offset + st.tile * C;
+    };
+    uint32_t b = blockIdx.x;
+    TileJob cur, nxt;
+    SubTree st, stn;
+    uint64_t raw[16], ahead[16];
+    bool have = next_job(b, lm, tiles, cur);
+    if (have) fntt_col_load<S1, RA>(raw, tile_base(cur, st), st.n2);
+    while (have) {
+        uint32_t bn = b + gridDim.x;
+        const bool more = next_job(bn, lm, tiles, nxt);
+        if (more) fntt_col_load<S1, RA>(ahead, tile_base(nxt, stn), stn.n2);
+        uint64_t *base = tile_base(cur, st);
+        const DModulus mod = T.mod[cur.tidx];
+        const tw_t *tw = T.tw + static_cast<size_t>(cur.tidx) * n;
+        if (use_fp64(T, mod))
+            fntt_col_body<S1, RA>(lds, raw, base, tw, st.n2, st.root, FpField(mod));
+        else
+            fntt_col_body<S1, RA>(lds, raw, base, tw, st.n2, st.root, IntField<NARROW>(mod));
+        if (!more) break;
+        __syncthreads();  // the LDS image is free again
+        copy16(raw, ahead);
+        cur = nxt;
+        b = bn;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // forward, row phase: stages m = 2^S1 .. N/2, final reduction to [0,q), optional fused epilogue
 // ---------------------------------------------------------------------------------------------
+template <int S2, int RA>
+__device__ __forceinline__ void fntt_row_load(uint64_t (&raw)[16], const uint64_t *base) {
+    constexpr int RB = S2 - RA, L = 1 << S2, GC = 16 >> RA;
+#pragma unroll
+    for (int g = 0; g < GC; g++) {
+        const uint32_t gid = threadIdx.x + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) raw[(g << RA) + j] = base[a * L + ((j << RB) | b_lo)];
+    }
+}
 template <int S2, int RA, int EPI, class F>
-__device__ __forceinline__ void fntt_row_body(uint64_t *lds, uint64_t *base, const tw_t *tw_raw, const tw_t *twd_raw,
-                                              uint32_t n1, uint32_t ti, const F &f, uint64_t q, uint64_t *out,
-                                              const uint64_t *sub, const uint64_t *addend, uint64_t cst,
+__device__ __forceinline__ void fntt_row_body(uint64_t *lds, const uint64_t (&raw)[16], const tw_t *tw_raw,
+                                              const tw_t *twd_raw, uint32_t n1, uint32_t ti, const F &f, uint64_t q,
+                                              uint64_t *out, const uint64_t *sub, const uint64_t *addend, uint64_t cst,
                                               uint64_t cst_shoup) {
     constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
     using TW = typename F::twl;
@@ -374,7 +441,7 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, uint64_t *base, con
         const uint32_t gid = t + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;
         typename F::elem x[1 << RA];
 #pragma unroll
-        for (int j = 0; j < (1 << RA); j++) x[j] = F::unraw(base[a * L + ((j << RB) | b_lo)]);
+        for (int j = 0; j < (1 << RA); j++) x[j] = F::unraw(raw[(g << RA) + j]);
         ct_radix<RA, 0>(x, CanonTw<TW>{tw, n1 + ti * RW + a}, f);
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) lds[lds_row(a * L + ((j << RB) | b_lo))] = F::raw(x[j]);
@@ -426,40 +493,58 @@ __global__ PHA_NTT_BOUNDS void fntt_row_kernel(uint64_t *data, size_t poly_strid
                                                             Epilogue ep) {
     __shared__ uint64_t lds[kLdsWords];
     const uint32_t n = 1u << T.log_n, n1 = n >> S2, tiles = n >> kTileLog;
-    BlockWork bw;
-    if (!decode_block(blockIdx.x, lm, tiles, bw)) return;
-    const uint32_t poly = bw.poly, ti = bw.ti;
-    uint32_t twr, tidx;
-    if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
-    const size_t limb_off = static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
-    uint64_t *base = data + poly * poly_stride + limb_off;
-    const DModulus mod = T.mod[tidx];
-    const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
-    const tw_t *twd = T.twD + static_cast<size_t>(tidx) * T.twD_stride;
-
-    uint64_t *out = base;
-    const uint64_t *sub = nullptr, *addend = nullptr;
-    uint64_t cst = 0, cst_shoup = 0;
-    if (EPI != EPI_NONE) {
-        out = ep.out + poly * ep.out_poly_stride + limb_off;
-        sub = ep.sub + poly * ep.sub_poly_stride + limb_off;
-        if (EPI == EPI_SUB_MUL_ADD && (ep.addend_every == 0 || poly % ep.addend_every == 0))
-            addend = ep.addend + poly * ep.out_poly_stride + limb_off;
-        cst = ep.cst[twr];
-        cst_shoup = ep.cst_shoup[twr];
+    auto limb_off = [&](const TileJob &j) { return static_cast<size_t>(j.twr) * n + static_cast<size_t>(j.ti) * kTile; };
+    uint32_t b = blockIdx.x;
+    TileJob cur, nxt;
+    uint64_t raw[16], ahead[16];
+    bool have = next_job(b, lm, tiles, cur);
+    if (have) fntt_row_load<S2, RA>(raw, data + cur.poly * poly_stride + limb_off(cur));
+    while (have) {
+        uint32_t bn = b + gridDim.x;
+        const bool more = next_job(bn, lm, tiles, nxt);
+        if (more) fntt_row_load<S2, RA>(ahead, data + nxt.poly * poly_stride + limb_off(nxt));
+        const uint32_t poly = cur.poly, twr = cur.twr;
+        const size_t off = limb_off(cur);
+        const DModulus mod = T.mod[cur.tidx];
+        const tw_t *tw = T.tw + static_cast<size_t>(cur.tidx) * n;
+        const tw_t *twd = T.twD + static_cast<size_t>(cur.tidx) * T.twD_stride;
+        uint64_t *out = data + poly * poly_stride + off;
+        const uint64_t *sub = nullptr, *addend = nullptr;
+        uint64_t cst = 0, cst_shoup = 0;
+        if (EPI != EPI_NONE) {
+            out = ep.out + poly * ep.out_poly_stride + off;
+            sub = ep.sub + poly * ep.sub_poly_stride + off;
+            if (EPI == EPI_SUB_MUL_ADD && (ep.addend_every == 0 || poly % ep.addend_every == 0))
+                addend = ep.addend + poly * ep.out_poly_stride + off;
+            cst = ep.cst[twr];
+            cst_shoup = ep.cst_shoup[twr];
+        }
+        if (use_fp64(T, mod))
+            fntt_row_body<S2, RA, EPI>(lds, raw, tw, twd, n1, cur.ti, FpField(mod), mod.value, out, sub, addend, cst, cst_shoup);
+        else
+            fntt_row_body<S2, RA, EPI>(lds, raw, tw, twd, n1, cur.ti, IntField<NARROW>(mod), mod.value, out, sub, addend, cst,
+                                       cst_shoup);
+        if (!more) break;
+        __syncthreads();
+        copy16(raw, ahead);
+        cur = nxt;
+        b = bn;
     }
-    if (use_fp64(T, mod))
-        fntt_row_body<S2, RA, EPI>(lds, base, tw, twd, n1, ti, FpField(mod), mod.value, out, sub, addend, cst, cst_shoup);
-    else
-        fntt_row_body<S2, RA, EPI>(lds, base, tw, twd, n1, ti, IntField<NARROW>(mod), mod.value, out, sub, addend, cst,
-                                   cst_shoup);
 }
 
 // ---------------------------------------------------------------------------------------------
 // inverse, row phase (first): stages m = N/2 .. 2^S1
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void intt_row_load(uint64_t (&raw)[16], const uint64_t *src) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + (i * kThreads + threadIdx.x) * 2);
+        raw[2 * i] = v.x;
+        raw[2 * i + 1] = v.y;
+    }
+}
 template <int S2, int RA, class F>
-__device__ __forceinline__ void intt_row_body(uint64_t *lds, uint64_t *dst, const uint64_t *src, const tw_t *tw_raw,
+__device__ __forceinline__ void intt_row_body(uint64_t *lds, const uint64_t (&raw)[16], uint64_t *dst, const tw_t *tw_raw,
                                               const tw_t *twd_raw, uint32_t n1, uint32_t ti, const F &f) {
     constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
     using TW = typename F::twl;
@@ -469,9 +554,8 @@ __device__ __forceinline__ void intt_row_body(uint64_t *lds, uint64_t *dst, cons
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint32_t e = (i * kThreads + t) * 2;
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + e);
-        lds[lds_row(e)] = F::raw(f.from_u64(v.x));
-        lds[lds_row(e + 1)] = F::raw(f.from_u64(v.y));
+        lds[lds_row(e)] = F::raw(f.from_u64(raw[2 * i]));
+        lds[lds_row(e + 1)] = F::raw(f.from_u64(raw[2 * i + 1]));
     }
     __syncthreads();
 #pragma unroll
@@ -505,28 +589,50 @@ __global__ PHA_NTT_BOUNDS void intt_row_kernel(uint64_t *out, const uint64_t *in
                                                             NttTables T, LimbMap lm) {
     __shared__ uint64_t lds[kLdsWords];
     const uint32_t n = 1u << T.log_n, n1 = n >> S2, tiles = n >> kTileLog;
-    BlockWork bw;
-    if (!decode_block(blockIdx.x, lm, tiles, bw)) return;
-    const uint32_t poly = bw.poly, ti = bw.ti;
-    uint32_t twr, tidx;
-    if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
-    const size_t off = poly * poly_stride + static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
-    const DModulus mod = T.mod[tidx];
-    const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
-    const tw_t *twd = T.twD + static_cast<size_t>(tidx) * T.twD_stride;
-    if (use_fp64(T, mod))
-        intt_row_body<S2, RA>(lds, out + off, in + off, tw, twd, n1, ti, FpField(mod));
-    else
-        intt_row_body<S2, RA>(lds, out + off, in + off, tw, twd, n1, ti, IntField<true>(mod));
+    auto tile_off = [&](const TileJob &j) {
+        return j.poly * poly_stride + static_cast<size_t>(j.twr) * n + static_cast<size_t>(j.ti) * kTile;
+    };
+    uint32_t b = blockIdx.x;
+    TileJob cur, nxt;
+    uint64_t raw[16], ahead[16];
+    bool have = next_job(b, lm, tiles, cur);
+    if (have) intt_row_load(raw, in + tile_off(cur));
+    while (have) {
+        uint32_t bn = b + gridDim.x;
+        const bool more = next_job(bn, lm, tiles, nxt);
+        if (more) intt_row_load(ahead, in + tile_off(nxt));
+        const DModulus mod = T.mod[cur.tidx];
+        const tw_t *tw = T.tw + static_cast<size_t>(cur.tidx) * n;
+        const tw_t *twd = T.twD + static_cast<size_t>(cur.tidx) * T.twD_stride;
+        if (use_fp64(T, mod))
+            intt_row_body<S2, RA>(lds, raw, out + tile_off(cur), tw, twd, n1, cur.ti, FpField(mod));
+        else
+            intt_row_body<S2, RA>(lds, raw, out + tile_off(cur), tw, twd, n1, cur.ti, IntField<true>(mod));
+        if (!more) break;
+        __syncthreads();
+        copy16(raw, ahead);
+        cur = nxt;
+        b = bn;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // inverse, column phase (last): stages m = 2^(S1-1) .. 1, N^-1, reduction to [0,q), optional scale
 // ---------------------------------------------------------------------------------------------
+template <int S1, int RA>
+__device__ __forceinline__ void intt_col_load(uint64_t (&raw)[16], const uint64_t *base, uint32_t n2) {
+    constexpr int RB = S1 - RA, C = kTile >> S1, GB = 16 >> RB;
+#pragma unroll
+    for (int g = 0; g < GB; g++) {
+        const uint32_t gid = threadIdx.x + kThreads * g, c = gid % C, r_hi = gid / C;
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) raw[(g << RB) + j] = base[static_cast<size_t>((r_hi << RB) | j) * n2 + c];
+    }
+}
 template <int S1, int RA, int EPI, bool SPLIT, class F>
-__device__ __forceinline__ void intt_col_body(uint64_t *lds, uint64_t *base, const tw_t *tw_raw, uint32_t n2, uint32_t root,
-                                              const F &f, uint64_t n_inv, uint64_t n_inv_shoup, uint64_t cst,
-                                              uint64_t cst_shoup) {
+__device__ __forceinline__ void intt_col_body(uint64_t *lds, const uint64_t (&raw)[16], uint64_t *base, const tw_t *tw_raw,
+                                              uint32_t n2, uint32_t root, const F &f, uint64_t n_inv, uint64_t n_inv_shoup,
+                                              uint64_t cst, uint64_t cst_shoup) {
     constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
     using TW = typename F::twl;
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
@@ -537,7 +643,7 @@ __device__ __forceinline__ void intt_col_body(uint64_t *lds, uint64_t *base, con
         const uint32_t gid = t + kThreads * g, c = gid % C, r_hi = gid / C;
         typename F::elem x[1 << RB];
 #pragma unroll
-        for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(base[static_cast<size_t>((r_hi << RB) | j) * n2 + c]);
+        for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(raw[(g << RB) + j]);
         gs_radix<RB, false>(x, CanonTw<TW>{tw, (root << RA) + r_hi}, f, ninv);
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) lds[lds_col<C, RB>((r_hi << RB) | j, c)] = F::raw(x[j]);
@@ -570,26 +676,41 @@ __global__ PHA_NTT_BOUNDS void intt_col_kernel(uint64_t *data, size_t poly_strid
     constexpr int C = kTile >> S1;
     __shared__ uint64_t lds[kLdsWords];
     const uint32_t n = 1u << T.log_n, tiles = n >> kTileLog;
-    BlockWork bw;
-    if (!decode_block(blockIdx.x, lm, tiles, bw)) return;
-    const uint32_t poly = bw.poly, ti = bw.ti;
-    uint32_t twr, tidx;
-    if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
-    const SubTree st = sub_tree<S1>(T, ti);
-    uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + st.offset + st.tile * C;
-    const DModulus mod = T.mod[tidx];
-    const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
-    const uint64_t n_inv = T.n_inv[tidx], n_inv_shoup = T.n_inv_shoup[tidx];
-    uint64_t cst = 0, cst_shoup = 0;
-    if (EPI == EPI_SCALE) {
-        cst = ep.cst[twr];
-        cst_shoup = ep.cst_shoup[twr];
+    auto tile_base = [&](const TileJob &j, SubTree &st) {
+        st = sub_tree<S1>(T, j.ti);
+        return data + j.poly * poly_stride + static_cast<size_t>(j.twr) * n + st.offset + st.tile * C;
+    };
+    uint32_t b = blockIdx.x;
+    TileJob cur, nxt;
+    SubTree st, stn;
+    uint64_t raw[16], ahead[16];
+    bool have = next_job(b, lm, tiles, cur);
+    if (have) intt_col_load<S1, RA>(raw, tile_base(cur, st), st.n2);
+    while (have) {
+        uint32_t bn = b + gridDim.x;
+        const bool more = next_job(bn, lm, tiles, nxt);
+        if (more) intt_col_load<S1, RA>(ahead, tile_base(nxt, stn), stn.n2);
+        uint64_t *base = tile_base(cur, st);
+        const DModulus mod = T.mod[cur.tidx];
+        const tw_t *tw = T.tw + static_cast<size_t>(cur.tidx) * n;
+        const uint64_t n_inv = T.n_inv[cur.tidx], n_inv_shoup = T.n_inv_shoup[cur.tidx];
+        uint64_t cst = 0, cst_shoup = 0;
+        if (EPI == EPI_SCALE) {
+            cst = ep.cst[cur.twr];
+            cst_shoup = ep.cst_shoup[cur.twr];
+        }
+        if (use_fp64(T, mod))
+            intt_col_body<S1, RA, EPI, SPLIT>(lds, raw, base, tw, st.n2, st.root, FpField(mod), n_inv, n_inv_shoup, cst,
+                                              cst_shoup);
+        else
+            intt_col_body<S1, RA, EPI, SPLIT>(lds, raw, base, tw, st.n2, st.root, IntField<true>(mod), n_inv, n_inv_shoup, cst,
+                                              cst_shoup);
+        if (!more) break;
+        __syncthreads();
+        copy16(raw, ahead);
+        cur = nxt;
+        b = bn;
     }
-    if (use_fp64(T, mod))
-        intt_col_body<S1, RA, EPI, SPLIT>(lds, base, tw, st.n2, st.root, FpField(mod), n_inv, n_inv_shoup, cst, cst_shoup);
-    else
-        intt_col_body<S1, RA, EPI, SPLIT>(lds, base, tw, st.n2, st.root, IntField<true>(mod), n_inv, n_inv_shoup, cst,
-                                          cst_shoup);
 }
 
 // ---------------------------------------------------------------------------------------------
