@@ -60,6 +60,8 @@ struct LimbMap {
     uint32_t digit_count;           // > 0 with digit_alpha: buffers are [batch][digit_count] and poly p is digit
                                     // p % digit_count (batched key switch)
     uint32_t xcd_map;               // 1: limb-to-XCD placement of decode_block (default), 0: tile-interleaved placement
+    uint32_t polys_magic;           // ceil(2^32 / polys): decode_block divides by polys with one multiply (set by
+                                    // the launcher; exact for dividends < 2^20 and polys <= 2^11)
 };
 
 struct NttTables {
@@ -93,16 +95,26 @@ enum : int { EPI_NONE = 0, EPI_SUB_MUL = 1, EPI_SUB_MUL_ADD = 2, EPI_SCALE = 3 }
 #ifndef PHA_NT_STORES
 #define PHA_NT_STORES 0
 #endif
+#ifndef PHA_SC1_STORES
+#define PHA_SC1_STORES 0
+#endif
 typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void st_stream(uint64_t *p, uint64_t v) {
-#if PHA_NT_STORES
+#if PHA_SC1_STORES >= 2
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+#elif PHA_NT_STORES
     __builtin_nontemporal_store(v, p);
 #else
     *p = v;
 #endif
 }
 __device__ __forceinline__ void st_stream2(uint64_t *p, ulonglong2 v) {
-#if PHA_NT_STORES
+#if PHA_SC1_STORES
+    // write-through (sc1) 16-B store: the bytes leave the XCD's L2 while the kernel runs instead of in the write-back
+    // at its end
+    const u64x2_t w = {v.x, v.y};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(w) : "memory");
+#elif PHA_NT_STORES
     u64x2_t w = {v.x, v.y};
     __builtin_nontemporal_store(w, reinterpret_cast<u64x2_t *>(p));
 #else
@@ -162,19 +174,24 @@ __host__ __device__ __forceinline__ uint32_t xcd_grid_blocks(uint32_t active, ui
 __device__ __forceinline__ bool decode_block(uint32_t b, const LimbMap &m, uint32_t tiles, BlockWork &w) {
     const uint32_t polys = m.polys, active = m.active;
     if (m.xcd_map) {
-        const uint32_t x = b & 7u, s = b >> 3, full = active >> 3, per_round = polys * tiles, main_part = full * per_round;
+        // tiles is a power of two and x / polys = umulhi(x, polys_magic): no integer division in the prologue (a u32
+        // division is ~40 VALU instructions; the round-1 decode ran five of them before the first global load)
+        const uint32_t tl = 31u - static_cast<uint32_t>(__builtin_clz(tiles));
+        const uint32_t x = b & 7u, s = b >> 3, full = active >> 3, main_part = (full * polys) << tl;
         if (s < main_part) {
-            const uint32_t k = s / per_round, rem = s % per_round;
+            const uint32_t k = __umulhi(s >> tl, m.polys_magic);       // s / (polys * tiles)
+            const uint32_t rem = s - ((k * polys) << tl);
             w.li = k * 8 + x;
-            w.ti = rem / polys;
-            w.poly = rem % polys;
+            w.ti = __umulhi(rem, m.polys_magic);
+            w.poly = rem - w.ti * polys;
             return true;
         }
-        const uint32_t s2 = s - main_part, v = (s2 / tiles) * 8 + x;
+        const uint32_t s2 = s - main_part, v = (s2 >> tl) * 8 + x;
         if (v >= (active & 7u) * polys) return false;
-        w.li = full * 8 + v / polys;
-        w.poly = v % polys;
-        w.ti = s2 % tiles;
+        const uint32_t vl = __umulhi(v, m.polys_magic);
+        w.li = full * 8 + vl;
+        w.poly = v - vl * polys;
+        w.ti = s2 & (tiles - 1);
         return true;
     }
     const uint32_t total_tiles = active * tiles;
@@ -287,9 +304,9 @@ struct SubTree {
 };
 template <int S1>
 __device__ __forceinline__ SubTree sub_tree(const NttTables &T, uint32_t ti) {
-    const uint32_t n_sub = (1u << T.log_n) >> T.split, tiles_sub = n_sub >> kTileLog;
-    const uint32_t h = ti / tiles_sub;
-    return SubTree{h * n_sub, ti % tiles_sub, n_sub >> S1, (1u << T.split) + h};
+    const uint32_t sub_log = T.log_n - T.split, n_sub = 1u << sub_log, tiles_log = sub_log - kTileLog;
+    const uint32_t h = ti >> tiles_log;
+    return SubTree{h << sub_log, ti & ((1u << tiles_log) - 1), n_sub >> S1, (1u << T.split) + h};
 }
 
 __device__ __forceinline__ bool use_fp64(const NttTables &T, const DModulus &mod) {
@@ -297,11 +314,27 @@ __device__ __forceinline__ bool use_fp64(const NttTables &T, const DModulus &mod
 }
 
 // ---------------------------------------------------------------------------------------------
+// Every kernel below issues the 16 global loads per lane of its tile FIRST and only then fetches what depends on the
+// limb (modulus, field choice, twiddles): per-workgroup timestamps (tools/scratch/trace_ntt.py) showed 40 % of a
+// launch's workgroups entering their load phase 2-4 us late, queued behind the other workgroups' tile loads for
+// the few bytes of T.mod[tidx] that selected their code path.
+// ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
 // forward, column phase: stages m = 1 .. 2^(S1-1)
 // ---------------------------------------------------------------------------------------------
+template <int S1, int RA>
+__device__ __forceinline__ void fntt_col_load(uint64_t (&raw)[16], const uint64_t *base, uint32_t n2) {
+    constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA;
+#pragma unroll
+    for (int g = 0; g < GA; g++) {
+        const uint32_t gid = threadIdx.x + kThreads * g, c = gid % C, r_lo = gid / C;
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) raw[(g << RA) + j] = base[static_cast<size_t>((j << RB) | r_lo) * n2 + c];
+    }
+}
 template <int S1, int RA, class F>
-__device__ __forceinline__ void fntt_col_body(uint64_t *lds, uint64_t *base, const tw_t *tw_raw, uint32_t n2, uint32_t root,
-                                              const F &f) {
+__device__ __forceinline__ void fntt_col_body(uint64_t *lds, const uint64_t (&raw)[16], uint64_t *base, const tw_t *tw_raw,
+                                              uint32_t n2, uint32_t root, const F &f) {
     constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
     using TW = typename F::twl;
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
@@ -312,7 +345,7 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, uint64_t *base, con
         const uint32_t gid = t + kThreads * g, c = gid % C, r_lo = gid / C;
         typename F::elem x[1 << RA];
 #pragma unroll
-        for (int j = 0; j < (1 << RA); j++) x[j] = f.from_u64(base[static_cast<size_t>((j << RB) | r_lo) * n2 + c]);
+        for (int j = 0; j < (1 << RA); j++) x[j] = f.from_u64(raw[(g << RA) + j]);
         ct_radix<RA, 0>(x, CanonTw<TW>{tw, root}, f);
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) lds[lds_col<C, RB>((j << RB) | r_lo, c)] = F::raw(x[j]);
@@ -349,21 +382,33 @@ __global__ PHA_NTT_BOUNDS void fntt_col_kernel(uint64_t *data, size_t poly_strid
     if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
     const SubTree st = sub_tree<S1>(T, ti);
     uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + st.offset + st.tile * C;
+    uint64_t raw[16];
+    fntt_col_load<S1, RA>(raw, base, st.n2);
     const DModulus mod = T.mod[tidx];
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     if (use_fp64(T, mod))
-        fntt_col_body<S1, RA>(lds, base, tw, st.n2, st.root, FpField(mod));
+        fntt_col_body<S1, RA>(lds, raw, base, tw, st.n2, st.root, FpField(mod));
     else
-        fntt_col_body<S1, RA>(lds, base, tw, st.n2, st.root, IntField<NARROW>(mod));
+        fntt_col_body<S1, RA>(lds, raw, base, tw, st.n2, st.root, IntField<NARROW>(mod));
 }
 
 // ---------------------------------------------------------------------------------------------
 // forward, row phase: stages m = 2^S1 .. N/2, final reduction to [0,q), optional fused epilogue
 // ---------------------------------------------------------------------------------------------
+template <int S2, int RA>
+__device__ __forceinline__ void fntt_row_load(uint64_t (&raw)[16], const uint64_t *base) {
+    constexpr int RB = S2 - RA, L = 1 << S2, GC = 16 >> RA;
+#pragma unroll
+    for (int g = 0; g < GC; g++) {
+        const uint32_t gid = threadIdx.x + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) raw[(g << RA) + j] = base[a * L + ((j << RB) | b_lo)];
+    }
+}
 template <int S2, int RA, int EPI, class F>
-__device__ __forceinline__ void fntt_row_body(uint64_t *lds, uint64_t *base, const tw_t *tw_raw, const tw_t *twd_raw,
-                                              uint32_t n1, uint32_t ti, const F &f, uint64_t q, uint64_t *out,
-                                              const uint64_t *sub, const uint64_t *addend, uint64_t cst,
+__device__ __forceinline__ void fntt_row_body(uint64_t *lds, const uint64_t (&raw)[16], const tw_t *tw_raw,
+                                              const tw_t *twd_raw, uint32_t n1, uint32_t ti, const F &f, uint64_t q,
+                                              uint64_t *out, const uint64_t *sub, const uint64_t *addend, uint64_t cst,
                                               uint64_t cst_shoup) {
     constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
     using TW = typename F::twl;
@@ -374,7 +419,7 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, uint64_t *base, con
         const uint32_t gid = t + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;
         typename F::elem x[1 << RA];
 #pragma unroll
-        for (int j = 0; j < (1 << RA); j++) x[j] = F::unraw(base[a * L + ((j << RB) | b_lo)]);
+        for (int j = 0; j < (1 << RA); j++) x[j] = F::unraw(raw[(g << RA) + j]);
         ct_radix<RA, 0>(x, CanonTw<TW>{tw, n1 + ti * RW + a}, f);
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) lds[lds_row(a * L + ((j << RB) | b_lo))] = F::raw(x[j]);
@@ -433,6 +478,8 @@ __global__ PHA_NTT_BOUNDS void fntt_row_kernel(uint64_t *data, size_t poly_strid
     if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
     const size_t limb_off = static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
     uint64_t *base = data + poly * poly_stride + limb_off;
+    uint64_t raw[16];
+    fntt_row_load<S2, RA>(raw, base);
     const DModulus mod = T.mod[tidx];
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     const tw_t *twd = T.twD + static_cast<size_t>(tidx) * T.twD_stride;
@@ -449,17 +496,25 @@ __global__ PHA_NTT_BOUNDS void fntt_row_kernel(uint64_t *data, size_t poly_strid
         cst_shoup = ep.cst_shoup[twr];
     }
     if (use_fp64(T, mod))
-        fntt_row_body<S2, RA, EPI>(lds, base, tw, twd, n1, ti, FpField(mod), mod.value, out, sub, addend, cst, cst_shoup);
+        fntt_row_body<S2, RA, EPI>(lds, raw, tw, twd, n1, ti, FpField(mod), mod.value, out, sub, addend, cst, cst_shoup);
     else
-        fntt_row_body<S2, RA, EPI>(lds, base, tw, twd, n1, ti, IntField<NARROW>(mod), mod.value, out, sub, addend, cst,
+        fntt_row_body<S2, RA, EPI>(lds, raw, tw, twd, n1, ti, IntField<NARROW>(mod), mod.value, out, sub, addend, cst,
                                    cst_shoup);
 }
 
 // ---------------------------------------------------------------------------------------------
 // inverse, row phase (first): stages m = N/2 .. 2^S1
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void intt_row_load(uint64_t (&raw)[16], const uint64_t *src) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + (i * kThreads + threadIdx.x) * 2);
+        raw[2 * i] = v.x;
+        raw[2 * i + 1] = v.y;
+    }
+}
 template <int S2, int RA, class F>
-__device__ __forceinline__ void intt_row_body(uint64_t *lds, uint64_t *dst, const uint64_t *src, const tw_t *tw_raw,
+__device__ __forceinline__ void intt_row_body(uint64_t *lds, const uint64_t (&raw)[16], uint64_t *dst, const tw_t *tw_raw,
                                               const tw_t *twd_raw, uint32_t n1, uint32_t ti, const F &f) {
     constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
     using TW = typename F::twl;
@@ -469,9 +524,8 @@ __device__ __forceinline__ void intt_row_body(uint64_t *lds, uint64_t *dst, cons
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint32_t e = (i * kThreads + t) * 2;
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + e);
-        lds[lds_row(e)] = F::raw(f.from_u64(v.x));
-        lds[lds_row(e + 1)] = F::raw(f.from_u64(v.y));
+        lds[lds_row(e)] = F::raw(f.from_u64(raw[2 * i]));
+        lds[lds_row(e + 1)] = F::raw(f.from_u64(raw[2 * i + 1]));
     }
     __syncthreads();
 #pragma unroll
@@ -511,22 +565,34 @@ __global__ PHA_NTT_BOUNDS void intt_row_kernel(uint64_t *out, const uint64_t *in
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
     const size_t off = poly * poly_stride + static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
+    uint64_t raw[16];
+    intt_row_load(raw, in + off);
     const DModulus mod = T.mod[tidx];
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     const tw_t *twd = T.twD + static_cast<size_t>(tidx) * T.twD_stride;
     if (use_fp64(T, mod))
-        intt_row_body<S2, RA>(lds, out + off, in + off, tw, twd, n1, ti, FpField(mod));
+        intt_row_body<S2, RA>(lds, raw, out + off, tw, twd, n1, ti, FpField(mod));
     else
-        intt_row_body<S2, RA>(lds, out + off, in + off, tw, twd, n1, ti, IntField<true>(mod));
+        intt_row_body<S2, RA>(lds, raw, out + off, tw, twd, n1, ti, IntField<true>(mod));
 }
 
 // ---------------------------------------------------------------------------------------------
 // inverse, column phase (last): stages m = 2^(S1-1) .. 1, N^-1, reduction to [0,q), optional scale
 // ---------------------------------------------------------------------------------------------
+template <int S1, int RA>
+__device__ __forceinline__ void intt_col_load(uint64_t (&raw)[16], const uint64_t *base, uint32_t n2) {
+    constexpr int RB = S1 - RA, C = kTile >> S1, GB = 16 >> RB;
+#pragma unroll
+    for (int g = 0; g < GB; g++) {
+        const uint32_t gid = threadIdx.x + kThreads * g, c = gid % C, r_hi = gid / C;
+#pragma unroll
+        for (int j = 0; j < (1 << RB); j++) raw[(g << RB) + j] = base[static_cast<size_t>((r_hi << RB) | j) * n2 + c];
+    }
+}
 template <int S1, int RA, int EPI, bool SPLIT, class F>
-__device__ __forceinline__ void intt_col_body(uint64_t *lds, uint64_t *base, const tw_t *tw_raw, uint32_t n2, uint32_t root,
-                                              const F &f, uint64_t n_inv, uint64_t n_inv_shoup, uint64_t cst,
-                                              uint64_t cst_shoup) {
+__device__ __forceinline__ void intt_col_body(uint64_t *lds, const uint64_t (&raw)[16], uint64_t *base, const tw_t *tw_raw,
+                                              uint32_t n2, uint32_t root, const F &f, uint64_t n_inv, uint64_t n_inv_shoup,
+                                              uint64_t cst, uint64_t cst_shoup) {
     constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
     using TW = typename F::twl;
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
@@ -537,7 +603,7 @@ __device__ __forceinline__ void intt_col_body(uint64_t *lds, uint64_t *base, con
         const uint32_t gid = t + kThreads * g, c = gid % C, r_hi = gid / C;
         typename F::elem x[1 << RB];
 #pragma unroll
-        for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(base[static_cast<size_t>((r_hi << RB) | j) * n2 + c]);
+        for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(raw[(g << RB) + j]);
         gs_radix<RB, false>(x, CanonTw<TW>{tw, (root << RA) + r_hi}, f, ninv);
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) lds[lds_col<C, RB>((r_hi << RB) | j, c)] = F::raw(x[j]);
@@ -577,6 +643,8 @@ __global__ PHA_NTT_BOUNDS void intt_col_kernel(uint64_t *data, size_t poly_strid
     if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
     const SubTree st = sub_tree<S1>(T, ti);
     uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + st.offset + st.tile * C;
+    uint64_t raw[16];
+    intt_col_load<S1, RA>(raw, base, st.n2);
     const DModulus mod = T.mod[tidx];
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     const uint64_t n_inv = T.n_inv[tidx], n_inv_shoup = T.n_inv_shoup[tidx];
@@ -586,9 +654,9 @@ __global__ PHA_NTT_BOUNDS void intt_col_kernel(uint64_t *data, size_t poly_strid
         cst_shoup = ep.cst_shoup[twr];
     }
     if (use_fp64(T, mod))
-        intt_col_body<S1, RA, EPI, SPLIT>(lds, base, tw, st.n2, st.root, FpField(mod), n_inv, n_inv_shoup, cst, cst_shoup);
+        intt_col_body<S1, RA, EPI, SPLIT>(lds, raw, base, tw, st.n2, st.root, FpField(mod), n_inv, n_inv_shoup, cst, cst_shoup);
     else
-        intt_col_body<S1, RA, EPI, SPLIT>(lds, base, tw, st.n2, st.root, IntField<true>(mod), n_inv, n_inv_shoup, cst,
+        intt_col_body<S1, RA, EPI, SPLIT>(lds, raw, base, tw, st.n2, st.root, IntField<true>(mod), n_inv, n_inv_shoup, cst,
                                           cst_shoup);
 }
 

@@ -337,20 +337,29 @@ void launch_icol(int epi, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, 
         default: CALL8; break;                 \
     }
 
-uint32_t ntt_grid_blocks(const pha_context *ctx, uint32_t active, size_t polys, size_t tiles) {
+// limb-to-XCD placement needs the launch inside the range of decode_block's multiply-by-reciprocal division
+bool use_xcd_map(const pha_context *ctx, uint32_t active, size_t polys, size_t tiles) {
+    return ctx->xcd_map && polys <= 2048 && static_cast<uint64_t>(active + 8) * polys * tiles < (1ull << 22);
+}
+uint32_t ntt_grid_blocks(bool xcd, uint32_t active, size_t polys, size_t tiles) {
     const uint32_t p = static_cast<uint32_t>(polys), t = static_cast<uint32_t>(tiles);
-    return ctx->xcd_map ? xcd_grid_blocks(active, p, t) : active * p * t;
+    return xcd ? xcd_grid_blocks(active, p, t) : active * p * t;
+}
+void set_placement(LimbMap &lm, bool xcd, size_t polys) {
+    lm.polys = static_cast<uint32_t>(polys);
+    lm.xcd_map = xcd ? 1u : 0u;
+    lm.polys_magic = static_cast<uint32_t>(((1ull << 32) + polys - 1) / polys);
 }
 int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stride, const NttRange &r, int epi,
                 const Epilogue &ep, hipStream_t st, int phases = 3) {
     if (!r.active || !polys) return PHA_OK;
     const NttTables T = ctx->fwd_tables();
     NttRange rr = r;
-    rr.lm.polys = static_cast<uint32_t>(polys);
-    rr.lm.xcd_map = ctx->xcd_map;
-    const dim3 grid(ntt_grid_blocks(ctx, r.active, polys, ctx->n >> kTileLog));
+    const bool xcd = use_xcd_map(ctx, r.active, polys, ctx->n >> kTileLog);
+    set_placement(rr.lm, xcd, polys);
+    const dim3 grid(ntt_grid_blocks(xcd, r.active, polys, ctx->n >> kTileLog));
     if ((phases & 1) && T.split)
-        hipLaunchKernelGGL(split_fwd_kernel, dim3(ntt_grid_blocks(ctx, r.active, polys, ctx->n >> 13)), dim3(256), 0, st,
+        hipLaunchKernelGGL(split_fwd_kernel, dim3(ntt_grid_blocks(xcd, r.active, polys, ctx->n >> 13)), dim3(256), 0, st,
                            data, poly_stride, T, rr.lm);
     if (phases & 1)
     DISPATCH_S(ctx->plan.s1, 0, (launch_fcol<6, 3>(ctx->narrow, grid, st, data, poly_stride, T, rr.lm)),
@@ -368,9 +377,9 @@ int ntt_backward(pha_context *ctx, uint64_t *out, const uint64_t *in, size_t pol
     if (!r.active || !polys) return PHA_OK;
     const NttTables T = ctx->inv_tables();
     NttRange rr = r;
-    rr.lm.polys = static_cast<uint32_t>(polys);
-    rr.lm.xcd_map = ctx->xcd_map;
-    const dim3 grid(ntt_grid_blocks(ctx, r.active, polys, ctx->n >> kTileLog));
+    const bool xcd = use_xcd_map(ctx, r.active, polys, ctx->n >> kTileLog);
+    set_placement(rr.lm, xcd, polys);
+    const dim3 grid(ntt_grid_blocks(xcd, r.active, polys, ctx->n >> kTileLog));
     if (phases & 2)
     DISPATCH_S(ctx->plan.s2, 0, (launch_irow<6, 3>(grid, st, out, in, poly_stride, T, rr.lm)),
                (launch_irow<7, 4>(grid, st, out, in, poly_stride, T, rr.lm)),
