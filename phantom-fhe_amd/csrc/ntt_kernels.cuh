@@ -171,6 +171,10 @@ __host__ __device__ __forceinline__ uint32_t xcd_grid_blocks(uint32_t active, ui
     const uint32_t full = active >> 3, left = (active & 7u) * polys;
     return 8u * (full * polys * tiles + ((left + 7u) >> 3) * tiles);
 }
+// x / polys for x < 2^20 (polys_magic = ceil(2^32 / polys) does not fit 32 bits for polys = 1)
+__device__ __forceinline__ uint32_t div_polys(uint32_t x, const LimbMap &m) {
+    return m.polys == 1 ? x : __umulhi(x, m.polys_magic);
+}
 __device__ __forceinline__ bool decode_block(uint32_t b, const LimbMap &m, uint32_t tiles, BlockWork &w) {
     const uint32_t polys = m.polys, active = m.active;
     if (m.xcd_map) {
@@ -179,16 +183,16 @@ __device__ __forceinline__ bool decode_block(uint32_t b, const LimbMap &m, uint3
         const uint32_t tl = 31u - static_cast<uint32_t>(__builtin_clz(tiles));
         const uint32_t x = b & 7u, s = b >> 3, full = active >> 3, main_part = (full * polys) << tl;
         if (s < main_part) {
-            const uint32_t k = __umulhi(s >> tl, m.polys_magic);       // s / (polys * tiles)
+            const uint32_t k = div_polys(s >> tl, m);                  // s / (polys * tiles)
             const uint32_t rem = s - ((k * polys) << tl);
             w.li = k * 8 + x;
-            w.ti = __umulhi(rem, m.polys_magic);
+            w.ti = div_polys(rem, m);
             w.poly = rem - w.ti * polys;
             return true;
         }
         const uint32_t s2 = s - main_part, v = (s2 >> tl) * 8 + x;
         if (v >= (active & 7u) * polys) return false;
-        const uint32_t vl = __umulhi(v, m.polys_magic);
+        const uint32_t vl = div_polys(v, m);
         w.li = full * 8 + vl;
         w.poly = v - vl * polys;
         w.ti = s2 & (tiles - 1);
