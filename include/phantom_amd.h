@@ -174,6 +174,8 @@ int pha_apply_galois_inplace(pha_context *ctx, size_t chain_index, uint64_t *ct,
  * dst[2][l-1][N] from src[2][l][N]; src is preserved (the reference copies first) */
 int pha_rescale_to_next(pha_context *ctx, size_t chain_index, const uint64_t *src, size_t cipher_size,
                         uint64_t *dst, pha_stream_t stream);
+/* Uploads the per-level constants of chain_index (DRNSTool, src/rns.cu:11-192) now instead of on first use. */
+int pha_prepare_level(pha_context *ctx, size_t chain_index);
 
 /* ---- limb-parallel key switch and rescale ---------------------------------
  * No counterpart in the reference, which is single-GPU: these are the per-rank steps of the

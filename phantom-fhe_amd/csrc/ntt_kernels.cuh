@@ -60,6 +60,9 @@ struct LimbMap {
     uint32_t digit_count;           // > 0 with digit_alpha: buffers are [batch][digit_count] and poly p is digit
                                     // p % digit_count (batched key switch)
     uint32_t xcd_map;               // 1: limb-to-XCD placement of decode_block (default), 0: tile-interleaved placement
+    uint32_t out_limb0;             // inverse transform: buffer limb l of the input lands on limb l - out_limb0 of the
+    size_t out_poly_stride;         // output, whose polys are out_poly_stride words apart (0: the input's stride) --
+                                    // e.g. the last limb of every poly gathered into a [polys][N] buffer (rescale)
     uint32_t polys_magic;           // ceil(2^32 / polys): decode_block divides by polys with one multiply (set by
                                     // the launcher; exact for dividends < 2^20 and polys <= 2^11)
 };
@@ -82,7 +85,8 @@ struct Epilogue {
     uint64_t *out;
     const uint64_t *sub;
     const uint64_t *addend;
-    const uint64_t *cst, *cst_shoup;  // indexed by absolute buffer limb
+    const uint64_t *cst, *cst_shoup;  // indexed by buffer limb - cst_limb0
+    uint32_t cst_limb0;
     size_t out_poly_stride, sub_poly_stride;
     uint32_t addend_every;  // > 0: only polys p with p % addend_every == 0 take the addend (a rotation adds pi(c0) to
                             // the first poly of each ciphertext and nothing to the second)
@@ -313,6 +317,11 @@ __device__ __forceinline__ SubTree sub_tree(const NttTables &T, uint32_t ti) {
     return SubTree{h << sub_log, ti & ((1u << tiles_log) - 1), n_sub >> S1, (1u << T.split) + h};
 }
 
+// where limb twr of poly `poly` lives in the output buffer of an inverse transform (see LimbMap::out_limb0)
+__device__ __forceinline__ size_t inv_out_offset(const LimbMap &lm, uint32_t poly, size_t poly_stride, uint32_t twr, uint32_t n) {
+    return poly * (lm.out_poly_stride ? lm.out_poly_stride : poly_stride) + static_cast<size_t>(twr - lm.out_limb0) * n;
+}
+
 __device__ __forceinline__ bool use_fp64(const NttTables &T, const DModulus &mod) {
     return T.fp64 && (mod.value >> 50) == 0;
 }
@@ -496,8 +505,8 @@ __global__ PHA_NTT_BOUNDS void fntt_row_kernel(uint64_t *data, size_t poly_strid
         sub = ep.sub + poly * ep.sub_poly_stride + limb_off;
         if (EPI == EPI_SUB_MUL_ADD && (ep.addend_every == 0 || poly % ep.addend_every == 0))
             addend = ep.addend + poly * ep.out_poly_stride + limb_off;
-        cst = ep.cst[twr];
-        cst_shoup = ep.cst_shoup[twr];
+        cst = ep.cst[twr - ep.cst_limb0];
+        cst_shoup = ep.cst_shoup[twr - ep.cst_limb0];
     }
     if (use_fp64(T, mod))
         fntt_row_body<S2, RA, EPI>(lds, raw, tw, twd, n1, ti, FpField(mod), mod.value, out, sub, addend, cst, cst_shoup);
@@ -569,15 +578,16 @@ __global__ PHA_NTT_BOUNDS void intt_row_kernel(uint64_t *out, const uint64_t *in
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
     const size_t off = poly * poly_stride + static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
+    const size_t out_off = inv_out_offset(lm, poly, poly_stride, twr, n) + static_cast<size_t>(ti) * kTile;
     uint64_t raw[16];
     intt_row_load(raw, in + off);
     const DModulus mod = T.mod[tidx];
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     const tw_t *twd = T.twD + static_cast<size_t>(tidx) * T.twD_stride;
     if (use_fp64(T, mod))
-        intt_row_body<S2, RA>(lds, raw, out + off, tw, twd, n1, ti, FpField(mod));
+        intt_row_body<S2, RA>(lds, raw, out + out_off, tw, twd, n1, ti, FpField(mod));
     else
-        intt_row_body<S2, RA>(lds, raw, out + off, tw, twd, n1, ti, IntField<true>(mod));
+        intt_row_body<S2, RA>(lds, raw, out + out_off, tw, twd, n1, ti, IntField<true>(mod));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -646,7 +656,7 @@ __global__ PHA_NTT_BOUNDS void intt_col_kernel(uint64_t *data, size_t poly_strid
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
     const SubTree st = sub_tree<S1>(T, ti);
-    uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + st.offset + st.tile * C;
+    uint64_t *base = data + inv_out_offset(lm, poly, poly_stride, twr, n) + st.offset + st.tile * C;
     uint64_t raw[16];
     intt_col_load<S1, RA>(raw, base, st.n2);
     const DModulus mod = T.mod[tidx];
@@ -654,8 +664,8 @@ __global__ PHA_NTT_BOUNDS void intt_col_kernel(uint64_t *data, size_t poly_strid
     const uint64_t n_inv = T.n_inv[tidx], n_inv_shoup = T.n_inv_shoup[tidx];
     uint64_t cst = 0, cst_shoup = 0;
     if (EPI == EPI_SCALE) {
-        cst = ep.cst[twr];
-        cst_shoup = ep.cst_shoup[twr];
+        cst = ep.cst[twr - ep.cst_limb0];
+        cst_shoup = ep.cst_shoup[twr - ep.cst_limb0];
     }
     if (use_fp64(T, mod))
         intt_col_body<S1, RA, EPI, SPLIT>(lds, raw, base, tw, st.n2, st.root, FpField(mod), n_inv, n_inv_shoup, cst, cst_shoup);
@@ -705,11 +715,11 @@ __global__ __launch_bounds__(256) void split_inv_kernel(uint64_t *data, size_t p
     const uint32_t poly = bw.poly, ti = bw.ti;
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
-    uint64_t *lo = data + poly * poly_stride + static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * 4096, *hi = lo + half;
+    uint64_t *lo = data + inv_out_offset(lm, poly, poly_stride, twr, n) + static_cast<size_t>(ti) * 4096, *hi = lo + half;
     const DModulus mod = T.mod[tidx];
     const uint64_t q = mod.value, w = root_twiddle(T, mod, T.tw + static_cast<size_t>(tidx) * n);
     const uint64_t n_inv = T.n_inv[tidx];
-    const uint64_t cst = EPI == EPI_SCALE ? ep.cst[twr] : 0;
+    const uint64_t cst = EPI == EPI_SCALE ? ep.cst[twr - ep.cst_limb0] : 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint32_t e = (i * 256 + threadIdx.x) * 2;

@@ -153,6 +153,7 @@ struct pha_context {
     std::map<size_t, std::unique_ptr<EncoderLevel>> enc_levels;
 
     int num_cus = 0;
+    int device = -1;          // the device this context was created on
     uint32_t xcd_map = 1;     // limb-to-XCD block placement of the NTT kernels (PHA_XCD_MAP=0: tile-interleaved, round 1)
 
     NttTables fwd_tables() const {
@@ -372,11 +373,15 @@ int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stri
     return check_launch("forward NTT");
 }
 
+// out_limb0 / out_poly_stride: see LimbMap (where the transformed limbs land in `out`; default: where they were in `in`)
 int ntt_backward(pha_context *ctx, uint64_t *out, const uint64_t *in, size_t polys, size_t poly_stride,
-                 const NttRange &r, int epi, const Epilogue &ep, hipStream_t st, int phases = 3) {
+                 const NttRange &r, int epi, const Epilogue &ep, hipStream_t st, int phases = 3, size_t out_limb0 = 0,
+                 size_t out_poly_stride = 0) {
     if (!r.active || !polys) return PHA_OK;
     const NttTables T = ctx->inv_tables();
     NttRange rr = r;
+    rr.lm.out_limb0 = static_cast<uint32_t>(out_limb0);
+    rr.lm.out_poly_stride = out_poly_stride;
     const bool xcd = use_xcd_map(ctx, r.active, polys, ctx->n >> kTileLog);
     set_placement(rr.lm, xcd, polys);
     const dim3 grid(ntt_grid_blocks(xcd, r.active, polys, ctx->n >> kTileLog));
@@ -596,8 +601,9 @@ int do_moddown(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *cx, uint
     } else {
         // INTT fused with bconv phase 1 (x PHatInv mod p_k); constants indexed by buffer limb
         Epilogue ep{};
-        ep.cst = lt->PHatInv.v.p - size_Ql;
-        ep.cst_shoup = lt->PHatInv.s.p - size_Ql;
+        ep.cst = lt->PHatInv.v.p;
+        ep.cst_shoup = lt->PHatInv.s.p;
+        ep.cst_limb0 = static_cast<uint32_t>(size_Ql);
         PHA_TRY(ntt_backward(ctx, cx, cx, polys, size_QlP * n, rp, EPI_SCALE, ep, st));
         BconvBatch bt{size_Ql * n, size_QlP * n, 0, 0, 0, nullptr, 0, 0, 0, 0};
         PHA_TRY(launch_bconv(ctx, delta, cp, lt->moddown_matrix.p, lt->moddown_obase_tidx.p, static_cast<uint32_t>(alpha),
@@ -665,8 +671,9 @@ int do_merged_moddown(pha_context *ctx, LevelTool *lt, uint64_t *out, uint64_t *
     NttRange rb;
     PHA_TRY(make_range(ctx, alpha + 1, out_l, ctx->size_QP, alpha, 0, 0, rb));
     Epilogue ep{};
-    ep.cst = lt->merged.BHatInv.v.p - out_l;  // indexed by absolute buffer limb
-    ep.cst_shoup = lt->merged.BHatInv.s.p - out_l;
+    ep.cst = lt->merged.BHatInv.v.p;
+    ep.cst_shoup = lt->merged.BHatInv.s.p;
+    ep.cst_limb0 = static_cast<uint32_t>(out_l);
     PHA_TRY(ntt_backward(ctx, cx, cx, polys, size_QlP * n, rb, EPI_SCALE, ep, st));
     {   // exact, centred base conversion B -> Q_{l-1} (bconv_centred_kernel): the division below rounds to nearest
         const uint32_t n32 = static_cast<uint32_t>(n), obase = static_cast<uint32_t>(out_l);
@@ -732,6 +739,17 @@ int do_rescale(pha_context *ctx, LevelTool *lt, const uint64_t *src, const uint6
     ep.out_poly_stride = next * n;
     ep.sub_poly_stride = size_Ql * n;
     return ntt_forward(ctx, dst, cipher_size, next * n, r, EPI_SUB_MUL, ep, st);
+}
+
+// rescale_to_next (src/evaluate.cu:585-616, src/rns.cu:1157-1181) with the caller's scratch [cipher_size][n]: the last limb of
+// every poly is inverted into it (one launch), then broadcast over the remaining limbs and divided out
+int rescale_with_scratch(pha_context *ctx, LevelTool *lt, const uint64_t *src, size_t cipher_size, uint64_t *dst, uint64_t *ws,
+                         hipStream_t st) {
+    const size_t n = ctx->n, size_Ql = lt->size_Ql;
+    NttRange r;
+    PHA_TRY(make_range(ctx, 1, size_Ql - 1, 0, 0, 0, 0, r));
+    PHA_TRY(ntt_backward(ctx, ws, src, cipher_size, size_Ql * n, r, EPI_NONE, Epilogue{}, st, 3, size_Ql - 1, n));
+    return do_rescale(ctx, lt, src, ws, n, cipher_size, dst, st);
 }
 
 // ---- limb-parallel key switch -----------------------------------------------
@@ -839,8 +857,9 @@ int lp_moddown_begin(pha_context *ctx, LevelTool *lt, uint64_t *cx, const LimbWi
     PHA_TRY(make_p_window(ctx, lt, w, rp));
     Epilogue ep{};
     if (ctx->size_P == 1) return ntt_backward(ctx, cx, cx, 2, size_QlP * n, rp, EPI_NONE, ep, st);
-    ep.cst = lt->PHatInv.v.p - size_Ql;
-    ep.cst_shoup = lt->PHatInv.s.p - size_Ql;
+    ep.cst = lt->PHatInv.v.p;
+    ep.cst_shoup = lt->PHatInv.s.p;
+    ep.cst_limb0 = static_cast<uint32_t>(size_Ql);
     return ntt_backward(ctx, cx, cx, 2, size_QlP * n, rp, EPI_SCALE, ep, st);
 }
 
@@ -1140,8 +1159,9 @@ int pha_context_create(int log_n, const uint64_t *moduli_QP, size_t size_QP, siz
         ctx->xcd_map = env_u("PHA_XCD_MAP", 1) ? 1u : 0u;
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            ctx->num_cus = prop.multiProcessorCount;
+        HIP_TRY(hipGetDevice(&dev));
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+        ctx->device = dev;
     }
     ctx->narrow = true;
     for (size_t i = 0; i < size_QP; i++) ctx->narrow = ctx->narrow && (moduli_QP[i] >> 60) == 0;
@@ -1449,18 +1469,15 @@ int pha_rescale_to_next(pha_context *ctx, size_t chain_index, const uint64_t *sr
     LevelTool *lt;
     PHA_TRY(get_level(ctx, chain_index, &lt));
     if (lt->size_Ql < 2) return fail(PHA_ERR_INVALID_ARGUMENT, "end of modulus switching chain reached");
-    const size_t n = ctx->n, size_Ql = lt->size_Ql;
-    hipStream_t st = as_stream(stream);
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, cipher_size * n, &ws));
-    // INTT of each poly's last limb, out of place into the workspace: view the workspace as a
-    // buffer whose limb (size_Ql-1) of poly p sits at ws + p*n
-    NttRange r;
-    PHA_TRY(make_range(ctx, 1, size_Ql - 1, 0, 0, 0, 0, r));
-    for (size_t p = 0; p < cipher_size; p++) {
-        PHA_TRY(ntt_backward(ctx, ws + p * n - (size_Ql - 1) * n, src + p * size_Ql * n, 1, 0, r, EPI_NONE, Epilogue{}, st));
-    }
-    return do_rescale(ctx, lt, src, ws, n, cipher_size, dst, st);
+    PHA_TRY(ensure_workspace(ctx, cipher_size * ctx->n, &ws));
+    return rescale_with_scratch(ctx, lt, src, cipher_size, dst, ws, as_stream(stream));
+}
+
+int pha_prepare_level(pha_context *ctx, size_t chain_index) {
+    REQUIRE_CTX(true);
+    LevelTool *lt;
+    return get_level(ctx, chain_index, &lt);
 }
 
 // ---- limb-parallel entry points (no counterpart in the single-GPU reference) ----
@@ -1515,10 +1532,8 @@ int pha_lp_rescale_begin(pha_context *ctx, size_t chain_index, const uint64_t *s
     const size_t n = ctx->n, size_Ql = lt->size_Ql;
     NttRange r;
     PHA_TRY(make_range(ctx, 1, size_Ql - 1, 0, 0, 0, 0, r));
-    for (size_t p = 0; p < cipher_size; p++)
-        PHA_TRY(ntt_backward(ctx, last_coeff + p * n - (size_Ql - 1) * n, src + p * size_Ql * n, 1, 0, r, EPI_NONE,
-                             Epilogue{}, as_stream(stream)));
-    return PHA_OK;
+    return ntt_backward(ctx, last_coeff, src, cipher_size, size_Ql * n, r, EPI_NONE, Epilogue{}, as_stream(stream), 3,
+                        size_Ql - 1, n);
 }
 
 int pha_lp_rescale_finish(pha_context *ctx, size_t chain_index, const uint64_t *src, const uint64_t *last_coeff,
