@@ -174,6 +174,18 @@ int pha_apply_galois_inplace(pha_context *ctx, size_t chain_index, uint64_t *ct,
  * dst[2][l-1][N] from src[2][l][N]; src is preserved (the reference copies first) */
 int pha_rescale_to_next(pha_context *ctx, size_t chain_index, const uint64_t *src, size_t cipher_size,
                         uint64_t *dst, pha_stream_t stream);
+/* The same rescale for callers that cannot allocate.  No counterpart in the reference (which allocates its
+ * temporaries with cudaMallocAsync, src/evaluate.cu:585-616): it is for callers that must not reach hipMalloc /
+ * hipFree -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  The scratch that
+ * pha_rescale_to_next takes from the context's workspace (the inverted last limb of every poly, cipher_size * N
+ * words) lives in a file-scope device array of PHA_NOALLOC_SCRATCH_WORDS words (3 MiB per GPU) instead; a larger
+ * cipher_size * N is refused with PHA_ERR_INVALID_ARGUMENT, and a level whose constants are not on the device yet with
+ * PHA_ERR_LOGIC (pha_prepare_level uploads them; it allocates, so call it at set-up).  Output is bit-identical to
+ * pha_rescale_to_next.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
+ * contexts) race. */
+#define PHA_NOALLOC_SCRATCH_WORDS ((size_t)3 << 17)
+int pha_rescale_to_next_noalloc(pha_context *ctx, size_t chain_index, const uint64_t *src, size_t cipher_size,
+                                uint64_t *dst, pha_stream_t stream);
 /* Uploads the per-level constants of chain_index (DRNSTool, src/rns.cu:11-192) now instead of on first use. */
 int pha_prepare_level(pha_context *ctx, size_t chain_index);
 

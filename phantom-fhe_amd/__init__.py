@@ -75,6 +75,7 @@ SIGNATURES = {
     "pha_multiply_and_relin_inplace": (_int, [_vp, _sz, _vp, _vp, _vp, _vp]),
     "pha_apply_galois_inplace": (_int, [_vp, _sz, _vp, _u32, _vp, _vp]),
     "pha_rescale_to_next": (_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    "pha_rescale_to_next_noalloc": (_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "pha_prepare_level": (_int, [_vp, _sz]),
     "pha_gen_secretkey": (_int, [_vp, _u64, _vp, _vp]),
     "pha_encrypt_zero_symmetric": (_int, [_vp, _vp, _sz, _u64, _u64, _vp, _vp]),
@@ -358,6 +359,9 @@ class PhantomContext:
 
     def rescale_to_next(self, chain_index, src, cipher_size, dst):
         _check(lib().pha_rescale_to_next(self._h, chain_index, _ptr(src), cipher_size, _ptr(dst), _stream()))
+
+    def rescale_to_next_noalloc(self, chain_index, src, cipher_size, dst):
+        _check(lib().pha_rescale_to_next_noalloc(self._h, chain_index, _ptr(src), cipher_size, _ptr(dst), _stream()))
 
     def prepare_level(self, chain_index):
         _check(lib().pha_prepare_level(self._h, chain_index))

@@ -23,7 +23,17 @@
 
 using namespace pha;
 
+// Scratch of pha_rescale_to_next_noalloc, the one entry point that allocates nothing: the inverted last limbs of up to
+// three polys at N = 2^17 (3 MiB on every GPU the library runs on, until the process ends).  In host code `scratch`
+// is a stand-in, not a device address: pha_context_create resolves it once per device with hipGetSymbolAddress and
+// every host use goes through g_scratch_ptr[device].
+constexpr size_t kNoAllocScratchWords = PHA_NOALLOC_SCRATCH_WORDS;
+static __device__ __align__(256) uint64_t scratch[kNoAllocScratchWords];
+
 namespace {
+
+constexpr int kMaxDevices = 64;
+uint64_t *g_scratch_ptr[kMaxDevices] = {};
 
 thread_local std::string g_last_error;
 
@@ -1162,6 +1172,12 @@ int pha_context_create(int log_n, const uint64_t *moduli_QP, size_t size_QP, siz
         HIP_TRY(hipGetDevice(&dev));
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
         ctx->device = dev;
+        if (dev >= 0 && dev < kMaxDevices && !g_scratch_ptr[dev]) {
+            // this device's copy of the scratch array (every GPU holds its own, at its own address)
+            uint64_t *p = nullptr;
+            HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void **>(&p), HIP_SYMBOL(scratch)));
+            g_scratch_ptr[dev] = p;
+        }
     }
     ctx->narrow = true;
     for (size_t i = 0; i < size_QP; i++) ctx->narrow = ctx->narrow && (moduli_QP[i] >> 60) == 0;
@@ -1471,6 +1487,26 @@ int pha_rescale_to_next(pha_context *ctx, size_t chain_index, const uint64_t *sr
     if (lt->size_Ql < 2) return fail(PHA_ERR_INVALID_ARGUMENT, "end of modulus switching chain reached");
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, cipher_size * ctx->n, &ws));
+    return rescale_with_scratch(ctx, lt, src, cipher_size, dst, ws, as_stream(stream));
+}
+
+int pha_rescale_to_next_noalloc(pha_context *ctx, size_t chain_index, const uint64_t *src, size_t cipher_size, uint64_t *dst,
+                                pha_stream_t stream) {
+    REQUIRE_CTX(src && dst);
+    if (chain_index < 1 || chain_index > ctx->size_Q)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "chain_index %zu out of range [1, %zu]", chain_index, ctx->size_Q);
+    // the level's constants must be on the device already: uploading them allocates
+    auto it = ctx->levels.find(ctx->size_Q - (chain_index - 1));
+    if (it == ctx->levels.end())
+        return fail(PHA_ERR_LOGIC, "pha_rescale_to_next_noalloc: level %zu is not prepared (call pha_prepare_level first)",
+                    chain_index);
+    LevelTool *lt = it->second.get();
+    if (lt->size_Ql < 2) return fail(PHA_ERR_INVALID_ARGUMENT, "end of modulus switching chain reached");
+    if (cipher_size == 0 || cipher_size * ctx->n > kNoAllocScratchWords)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "pha_rescale_to_next_noalloc: cipher_size * N = %zu words exceeds the %zu-word scratch",
+                    cipher_size * ctx->n, kNoAllocScratchWords);
+    uint64_t *ws = ctx->device >= 0 && ctx->device < kMaxDevices ? g_scratch_ptr[ctx->device] : nullptr;
+    if (!ws) return fail(PHA_ERR_LOGIC, "pha_rescale_to_next_noalloc: no scratch address for device %d", ctx->device);
     return rescale_with_scratch(ctx, lt, src, cipher_size, dst, ws, as_stream(stream));
 }
 
