@@ -1,25 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json metric on its configs[1]: batched RNS NTT/INTT, N = 2^16,
-36 limbs x 2 polys (uint64[2][36][65536]), one MI355X per rank.
+"""bench.py — BASELINE.json's metric on one node of MI355X GPUs, one process per GPU.
 
-A step = one forward NTT of the whole batch followed by one inverse NTT of it (the round trip
-keeps the buffer canonical), i.e. 144 limb-transforms through the C ABI
-(pha_ntt_forward_batched / pha_ntt_backward_batched).  Inputs are resident in HBM before the
-timed region.  value = limb-transforms per second over all ranks (weak scaling: every rank owns
-its own batch, the path has no exchange step, so no collective on the data path).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4]
 
-Extra objects on the JSON line:
-  roofline     — the dominant kernel (the forward row-phase kernel), timed live with HIP events
-                 on the launching stream; algorithmic bytes = N*8 read + N*8 write per limb per
-                 launch.  `transform_frac` is the same figure for the whole
-                 forward transform (both kernels of a limb-NTT share the 1 MiB of algorithmic
-                 bytes) — the number the >=60 % target is about.
-  cpu_baseline — the oracle (a scalar port; kind "port") timed on the host cores on a bounded
-                 sample of the same workload.
+--config 2 (default; BASELINE configs[1], the configuration `metric` is quoted on): batched RNS NTT/INTT, N = 2^16,
+    36 limbs x 2 polys (uint64[2][36][65536]) per GPU.  A step = one forward NTT of the whole batch followed by one
+    inverse NTT of it (144 limb-transforms through pha_ntt_forward_batched / pha_ntt_backward_batched; the round trip
+    keeps the buffer canonical).  value = limb-transforms per second over all ranks; weak scaling: every rank owns its
+    own batch, the path has no exchange step, so there is no collective on the data path.
+--config 3 (configs[2]): CKKS HMult + relinearise, N = 2^16, 36 + 12 limbs (dnum 3), the limbs sharded over the ranks
+    with RCCL all-gathers at the two base conversions (phantom-fhe_amd/limb_parallel.py).  value = ms per HMult+relin
+    (strong scaling).
+--config 4 (configs[3]): CKKS rotate on 64 independent ciphertexts dealt to the ranks; value = ciphertexts/s (strong
+    scaling, no data-path collective).
+
+With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) the script starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...` as a child
+process BEFORE anything touches the GPU and relays the child's JSON line; under a launcher it reads
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  `n_gpus` is the number of ranks that took part.
+
+Extra objects on the config-2 line:
+  roofline     — the forward transform (its two kernels, fntt_col_kernel + fntt_row_kernel), timed live with HIP events
+                 on the launching stream: achieved = algorithmic bytes (N*8 read + N*8 written per limb, SURVEY.md
+                 §8d) / time, frac = achieved / 8 TB/s.  `kernels` has every kernel's own average launch time and
+                 the rate at which it streams its limb once; `alu` prices the same transform against the measured
+                 32-bit multiply and FP64 issue peaks (the second bound north_star asks for); `traffic` is the
+                 fabric-side byte count of one forward transform from a separate rocprofv3 --pmc pass
+                 (tools/profile.sh -> profiles/traffic_latest.json), reported only when that file was produced from
+                 the kernel sources this run uses (hash of csrc/), else null.
+  cpu_baseline — the oracle (a scalar port; kind "port") timed on the host cores on a bounded sample of the same
+                 workload.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,31 +49,73 @@ N = 1 << LOG_N
 LIMBS = 36
 POLYS = 2
 BITS = [60] + [50] * 35  # BASELINE.md config 2 / SURVEY.md §8(d): first prime 60-bit, scale primes 50-bit
+SIZE_P = 12              # configs 3 / 4: 12 special primes of 60 bits (dnum 3)
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_LIMB = N * 8 * 2
+BUTTERFLIES_PER_LIMB = (N // 2) * LOG_N
+# measured issue peaks on MI355X (tools/ubench.hip, profiles/r1a_ubench.log), lane-operations per second chip-wide
+INT32_MUL_PEAK = 31.03e12    # v_mad_u64_u32
+FP64_PEAK = 36.74e12         # v_fma_f64
+MUL32_PER_INT_BUTTERFLY = 9      # csrc/modarith.cuh: approximate-quotient Shoup product
+FP64_PER_FP_BUTTERFLY = 10.3     # csrc/modarith.cuh FpField: 659 FP64 instructions per 64 butterflies in the ISA
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4))
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: CPU-side rehearsal of the launcher path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the HMult/rotate/bootstrap side measurements")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher rehearsal without a GPU: the ranks rendezvous, time an empty step and print the line")
     ap.add_argument("--pmc-traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
-                    help="per-launch HBM bytes of the dominant kernel from a separate rocprofv3 --pmc pass")
-    return ap.parse_args()
+                    help="fabric-side bytes per launch from a separate rocprofv3 --pmc pass (tools/profile.sh)")
+    return ap.parse_args(argv)
+
+
+def kernel_source_hash():
+    """Identifies the kernel sources a traffic file was measured on (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "phantom-fhe_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def shard_units(total_units, world, rank):
-    """Independent units (ciphertexts, config 4; batches here) are dealt to ranks in contiguous blocks,
+    """Independent units (ciphertexts, config 4; batches, config 2) are dealt to ranks in contiguous blocks,
     the first `total % world` ranks taking one more; no data-path collective."""
     base, extra = divmod(total_units, world)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def dist_setup(backend):
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a launcher: N ranks under torch.distributed.run as a CHILD process (never a re-exec: this
+    process has not touched the GPU, and must not before this point).  Relays the child's JSON line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif out.returncode == 0:
+        print(out.stdout, flush=True)
+    return out.returncode if lines or out.returncode else 1
+
+
+def dist_setup(backend, device_bound=True):
     """Returns (rank, world, local_rank, dist or None); RANK/WORLD_SIZE/MASTER_* come from the launcher."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -65,7 +124,7 @@ def dist_setup(backend):
     if world > 1:
         import torch
         import torch.distributed as dist
-        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" and device_bound else {}
         dist.init_process_group(backend, **kw)
     return rank, world, local_rank, dist
 
@@ -84,8 +143,28 @@ def aggregate_value(units_per_rank_step, steps, world, elapsed):
     return world * units_per_rank_step * steps / elapsed
 
 
+def timed_steps(step, steps, warmup, dist, sync, device):
+    """The contract's timed region: W untimed steps, then exactly K steps between barrier + synchronize on both
+    sides; returns the maximum over ranks of the elapsed seconds."""
+    def barrier():
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return max_over_ranks(time.perf_counter() - t0, dist, device)
+
+
 def event_time_ms(torch, fn, reps):
-    """Average duration of fn() over reps back-to-back launches, HIP events on the current stream."""
+    """Average duration of fn() over reps back-to-back launches, HIP events on the current stream (the stream the
+    library launches on: the bindings pass torch's current stream)."""
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
     for _ in range(reps):
@@ -108,12 +187,13 @@ def event_time_each_ms(torch, fn, reps):
 
 
 def cpu_baseline(mods, budget_s=12.0):
-    """Oracle forward+inverse over the same batch shape on the host cores (bounded sample)."""
+    """Oracle forward+inverse over the same batch shape on the host cores (bounded sample).  Threads: the box's CPU
+    share (OMP_NUM_THREADS as the harness sets it, 16 per GPU), never more than the machine has."""
     import numpy as np
 
     import oracle
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    threads = min(threads, os.cpu_count() or 1)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    threads = max(1, min(threads, os.cpu_count() or 1))
     os.environ["OMP_NUM_THREADS"] = str(threads)
     oracle.build()
     orc = oracle.Oracle(LOG_N, mods, 0)
@@ -129,8 +209,9 @@ def cpu_baseline(mods, budget_s=12.0):
         if el > budget_s:
             break
     return {"value": done / el, "unit": "limb-transforms/s", "cores": threads, "kind": "port",
+            "host_cores_visible": os.cpu_count(),
             "sample": f"{done} limb-transforms (36-limb poly, N=2^16, forward+inverse passes) in {el:.1f} s, "
-                      f"OpenMP over limbs"}
+                      f"OpenMP over limbs on {threads} threads (the box's CPU share for one GPU)"}
 
 
 def secondary_metrics(torch, pha):
@@ -138,7 +219,7 @@ def secondary_metrics(torch, pha):
     bootstrap (N=2^16, 64 slots), single GPU, event-timed."""
     import numpy as np
     res = {}
-    size_q, size_p = 36, 12
+    size_q, size_p = 36, SIZE_P
     mods = pha.coeff_modulus_create(N, [60] + [50] * (size_q - 1) + [60] * size_p)
     ctx = pha.PhantomContext(LOG_N, mods, size_p)
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -148,8 +229,8 @@ def secondary_metrics(torch, pha):
     ct1, ct2 = rnd(3, size_q), rnd(2, size_q)
     dst = torch.empty((2, size_q - 1, N), dtype=torch.int64, device="cuda")
 
-    def timed(fn, reps=20):
-        for _ in range(3):
+    def timed(fn, reps=50):
+        for _ in range(5):
             fn()
         torch.cuda.synchronize()
         return event_time_ms(torch, fn, reps)
@@ -157,6 +238,8 @@ def secondary_metrics(torch, pha):
     res["hmult_relin_ms"] = timed(lambda: ctx.multiply_and_relin_inplace(1, ct1, ct2, evk))
     res["rotate_ms"] = timed(lambda: ctx.apply_galois_inplace(1, ct2, 5, evk))
     res["rescale_ms"] = timed(lambda: ctx.rescale_to_next(1, ct2, 2, dst))
+    # ~0.9 GiB of algorithmic traffic per HMult + relinearise at these shapes
+    res["hmult_relin_roofline_frac"] = 0.9 * 2 ** 30 / (res["hmult_relin_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     res["config"] = "N=2^16, 36 Q limbs + 12 special primes (dnum 3), uniform synthetic ciphertexts and keys"
     ctx.close()
     del evk, ct1, ct2, dst
@@ -232,17 +315,60 @@ def secondary_metrics(torch, pha):
     return res
 
 
-def main():
-    args = parse()
+def roofline_config2(torch, ctx, buf, orig, mods, args):
+    """Live measurements behind the `roofline` object (rank 0, after the timed region)."""
+    reps = max(100, min(args.steps, 1000))
+    phase = {}
+    for name, inv, ph in (("fwd_col", 0, 0), ("fwd_row", 0, 1), ("inv_row", 1, 1), ("inv_col", 1, 0)):
+        fn = (lambda inv=inv, ph=ph: ctx.ntt_launch_phase(buf, POLYS, LIMBS, LIMBS, 0, inv, ph))
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        ms = event_time_ms(torch, fn, reps)
+        phase[name] = {"avg_launch_ms": ms, "median_ms_per_launch_events": event_time_each_ms(torch, fn, min(reps, 200)),
+                       # each kernel reads and writes every limb once: its own streaming rate
+                       "stream_GBs": POLYS * LIMBS * ALGO_BYTES_PER_LIMB / (ms * 1e-3) / 1e9}
+    buf.copy_(orig)
+    fwd = lambda: ctx.ntt_forward_batched(buf, POLYS, LIMBS, LIMBS, 0)  # noqa: E731
+    for _ in range(10):
+        fwd()
+    torch.cuda.synchronize()
+    fwd_ms = event_time_ms(torch, fwd, reps)
+    buf.copy_(orig)
+    algo = POLYS * LIMBS * ALGO_BYTES_PER_LIMB
+    achieved = algo / (fwd_ms * 1e-3) / 1e9
+    traffic, note = None, None
+    try:
+        with open(args.pmc_traffic_json) as f:
+            tj = json.load(f)
+        if tj.get("source_hash") == kernel_source_hash():
+            traffic = tj["fwd_col"] + tj["fwd_row"]
+        else:
+            note = "profiles/traffic_latest.json was measured on other kernel sources (source_hash differs): not reported"
+    except Exception as e:  # noqa: BLE001
+        note = f"no usable traffic file: {e!r}"[:160]
+    n_fp = sum(1 for q in mods if int(q) >> 50 == 0) * POLYS
+    n_int = POLYS * LIMBS - n_fp
+    t_int = n_int * BUTTERFLIES_PER_LIMB * MUL32_PER_INT_BUTTERFLY / INT32_MUL_PEAK
+    t_fp = n_fp * BUTTERFLIES_PER_LIMB * FP64_PER_FP_BUTTERFLY / FP64_PEAK
+    roof = {
+        "bound": "hbm", "kernel": "forward transform = fntt_col_kernel<8,4> + fntt_row_kernel<8,4,0>, 72 limbs per launch",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": fwd_ms,
+        "kernels": phase,
+        "alu": {"limbs_on_int32_path": n_int, "limbs_on_fp64_path": n_fp,
+                "mul32_lane_ops": n_int * BUTTERFLIES_PER_LIMB * MUL32_PER_INT_BUTTERFLY,
+                "fp64_lane_ops": n_fp * BUTTERFLIES_PER_LIMB * FP64_PER_FP_BUTTERFLY,
+                "int32_mul_peak_lane_ops_s": INT32_MUL_PEAK, "fp64_peak_lane_ops_s": FP64_PEAK,
+                "issue_floor_ms": 1e3 * (t_int + t_fp), "frac_of_alu_peak": (t_int + t_fp) / (fwd_ms * 1e-3)},
+    }
+    if note:
+        roof["traffic_note"] = note
+    return roof
+
+
+def run_config2(args, torch, pha, rank, world, dist):
     import numpy as np
-    import torch
-
-    import phantom_fhe_amd as pha
-
-    rank, world, local_rank, dist = dist_setup("nccl")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-
     mods = pha.coeff_modulus_create(N, BITS)
     ctx = pha.PhantomContext(LOG_N, mods, 0)
     # synthetic input: uniform residues, seeded per rank (data: synthetic)
@@ -255,82 +381,132 @@ def main():
         ctx.ntt_forward_batched(buf, POLYS, LIMBS, LIMBS, 0)
         ctx.ntt_backward_batched(buf, POLYS, LIMBS, LIMBS, 0)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, dist, "cuda")
+    elapsed = timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda")
     # size-independent property at full size: the round trips returned the input bit-for-bit
     assert torch.equal(buf, orig), "INTT(NTT(x)) != x after the timed region"
-
     units_per_step = 2 * POLYS * LIMBS
-    value = aggregate_value(units_per_step, args.steps, world, elapsed)
     out = {
         "metric": "RNS-NTT limb-transforms/s @N=2^16 (forward+inverse, 36 limbs x 2 polys per GPU)",
-        "value": value, "unit": "limb-transforms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "value": aggregate_value(units_per_step, args.steps, world, elapsed), "unit": "limb-transforms/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "configs[1]: batched RNS NTT+INTT, N=2^16, 36 limbs x 2 polys, uint64[2][36][65536] per GPU",
                    "limbs": LIMBS, "polys": POLYS, "log_n": LOG_N, "parallelism": f"independent batches x{world}"},
     }
-
     if rank == 0:
-        # dominant kernel, live: forward row-phase kernel over the whole batch, one launch = 72 limbs
-        reps = max(50, args.steps)
-        phase = {}
-        for name, inv, ph in (("fwd_col", 0, 0), ("fwd_row", 0, 1), ("inv_row", 1, 1), ("inv_col", 1, 0)):
-            fn = (lambda inv=inv, ph=ph: ctx.ntt_launch_phase(buf, POLYS, LIMBS, LIMBS, 0, inv, ph))
-            for _ in range(10):
-                fn()
-            torch.cuda.synchronize()
-            phase[name] = {"avg_ms_back_to_back": event_time_ms(torch, fn, reps),
-                           "median_ms_per_launch_events": event_time_each_ms(torch, fn, reps)}
-        buf.copy_(orig)
-        fwd_ms = event_time_ms(torch, lambda: ctx.ntt_forward_batched(buf, POLYS, LIMBS, LIMBS, 0), reps)
-        buf.copy_(orig)
-        dom = max(("fwd_col", "fwd_row"), key=lambda k: phase[k]["avg_ms_back_to_back"])
-        dom_ms = phase[dom]["avg_ms_back_to_back"]
-        algo = POLYS * LIMBS * ALGO_BYTES_PER_LIMB
-        achieved = algo / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        try:
-            with open(args.pmc_traffic_json) as f:
-                traffic = json.load(f).get(dom)
-        except Exception:
-            traffic = None
-        out["roofline"] = {
-            "bound": "hbm", "kernel": {"fwd_row": "fntt_row_kernel<8,4,0>", "fwd_col": "fntt_col_kernel<8,4>"}[dom],
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "algorithmic_bytes_per_launch": algo, "avg_launch_ms": dom_ms,
-            "transform_frac": algo / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "forward_transform_ms": fwd_ms,
-            "phases": phase,
-        }
+        out["roofline"] = roofline_config2(torch, ctx, buf, orig, mods, args)
         if not args.no_secondary and world == 1:
             # the other headline numbers of BASELINE.json (HMult+relin, rotate, bootstrap) on this GPU; they do
             # not enter `value`
             try:
                 ctx.close()
+                ctx = None
                 out["secondary"] = secondary_metrics(torch, pha)
-                ctx = pha.PhantomContext(LOG_N, mods, 0)
             except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline
                 out["secondary"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(mods)
+    if ctx is not None:
+        ctx.close()
+    return out
+
+
+def run_config3(args, torch, pha, rank, world, dist):
+    """HMult + relinearise with the limbs sharded over the ranks (strong scaling; RCCL all-gathers)."""
+    from phantom_fhe_amd.limb_parallel import LimbParallelEvaluator, ThreadComm, TorchDistComm
+    mods = pha.coeff_modulus_create(N, [60] + [50] * (LIMBS - 1) + [60] * SIZE_P)
+    ctx = pha.PhantomContext(LOG_N, mods, SIZE_P)
+    comm = TorchDistComm() if dist is not None else ThreadComm(ThreadComm.Shared(1), 0)
+    ev = LimbParallelEvaluator(ctx, comm)
+    g = torch.Generator(device="cuda").manual_seed(7)      # the same ciphertexts and key on every rank
+    lo = int(mods.min())
+    rnd = lambda *shape: torch.randint(0, lo, shape, dtype=torch.int64, device="cuda", generator=g)  # noqa: E731
+    ct1, ct2 = rnd(2, LIMBS, N), rnd(2, LIMBS, N)
+    out3 = torch.empty((3, LIMBS, N), dtype=torch.int64, device="cuda")
+    evk = pha.EvalKey([rnd(2, LIMBS + SIZE_P, N) for _ in range(ctx.beta(1))])
+
+    def step():
+        ev.multiply_and_relin(1, ct1, ct2, evk, out3)
+
+    elapsed = timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda")
+    q0, qc, p0, pc = ev.windows(1)[rank]
+    out = {
+        "metric": "CKKS HMult + relinearise ms @N=2^16, L=35 (36 + 12 limbs, dnum 3), limbs sharded over the GPUs",
+        "value": 1e3 * elapsed / args.steps, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "configs[2]: HMult + relinearise (hybrid key switch, dnum 3), N=2^16, 36 Q + 12 P limbs",
+                   "parallelism": f"limb-parallel x{world}: equal limb blocks, 1 + 2 in-place all-gathers per key switch",
+                   "rank0_window": {"q_begin": q0, "q_count": qc, "p_begin": p0, "p_count": pc}},
+    }
+    ctx.close()
+    return out
+
+
+def run_config4(args, torch, pha, rank, world, dist):
+    """Rotation of 64 independent ciphertexts dealt to the ranks (strong scaling; no collective)."""
+    total, batch = 64, 16
+    mods = pha.coeff_modulus_create(N, [60] + [50] * (LIMBS - 1) + [60] * SIZE_P)
+    ctx = pha.PhantomContext(LOG_N, mods, SIZE_P)
+    lo_u, hi_u = shard_units(total, world, rank)
+    g = torch.Generator(device="cuda").manual_seed(100 + rank)
+    small = int(mods.min())
+    rnd = lambda *shape: torch.randint(0, small, shape, dtype=torch.int64, device="cuda", generator=g)  # noqa: E731
+    cts = [rnd(2, LIMBS, N) for _ in range(lo_u, hi_u)]
+    groups = [torch.stack(cts[i:i + batch]) for i in range(0, len(cts), batch)]
+    evk = pha.EvalKey([rnd(2, LIMBS + SIZE_P, N) for _ in range(ctx.beta(1))])
+    elt = pha.galois_elt_from_step(LOG_N, 1)
+
+    def step():
+        for grp in groups:
+            ctx.apply_galois_batched(1, grp, elt, evk)
+
+    elapsed = timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda")
+    out = {
+        "metric": "CKKS rotate (apply_galois + key switch) ciphertexts/s, 64 independent ciphertexts @N=2^16, 36 + 12 limbs",
+        "value": total * args.steps / elapsed, "unit": "ciphertexts/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "configs[3]: rotate by one slot, 64 independent ciphertexts, N=2^16, 36 Q + 12 P limbs (dnum 3)",
+                   "parallelism": f"ciphertexts dealt to {world} ranks ({hi_u - lo_u} on rank 0), batches of {batch} per launch sequence"},
+    }
+    ctx.close()
+    return out
+
+
+def run_dry(args, rank, world, dist):
+    """Launcher rehearsal on CPU (tests/test_dist_cpu.py): same rendezvous, barrier, max-over-ranks and JSON line."""
+    elapsed = timed_steps(lambda: None, args.steps, args.warmup, dist, lambda: None, "cpu")
+    lo, hi = shard_units(64, world, rank)
+    return {"metric": "dry run (no GPU work)", "value": aggregate_value(1, args.steps, world, max(elapsed, 1e-9)), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "none", "rank0_units_of_64": hi - lo}}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+
+    if args.dry_run:
+        rank, world, local_rank, dist = dist_setup(args.backend, device_bound=False)
+        out = run_dry(args, rank, world, dist)
+    else:
+        import torch
+
+        import phantom_fhe_amd as pha
+
+        rank, world, local_rank, dist = dist_setup(args.backend)
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+        out = {2: run_config2, 3: run_config3, 4: run_config4}[args.config](args, torch, pha, rank, world, dist)
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
 
 
 if __name__ == "__main__":

@@ -214,13 +214,22 @@ int pha_lp_modup_finish(pha_context *ctx, size_t chain_index, uint64_t *t_mod_up
 int pha_lp_key_switch_inner_prod(pha_context *ctx, size_t chain_index, uint64_t *p_cx, const uint64_t *p_t_mod_up,
                                  const uint64_t *const *rlk, size_t q_begin, size_t q_count, size_t p_begin,
                                  size_t p_count, pha_stream_t stream);
-/* owned P limbs of both polys of cx: INTT and * PHatInv, in place (src/rns_bconv.cu:776-800) */
-int pha_lp_moddown_begin(pha_context *ctx, size_t chain_index, uint64_t *cx, size_t p_begin, size_t p_count,
+/* owned P limbs of both polys of cx: INTT and * PHatInv (src/rns_bconv.cu:776-800), written to
+ * p_coeff[2][p_coeff_poly_stride_limbs][N], owned limb p_begin + j at row row_begin + j -- the buffer the ranks
+ * all-gather in place (rank r's block of rows is block r of the buffer, whatever limbs it owns) */
+int pha_lp_moddown_begin(pha_context *ctx, size_t chain_index, const uint64_t *cx, uint64_t *p_coeff,
+                         size_t p_coeff_poly_stride_limbs, size_t row_begin, size_t p_begin, size_t p_count,
                          pha_stream_t stream);
-/* ct[owned] += (cx - NTT(bconv(gathered P limbs of cx))) * P^-1 (src/rns_bconv.cu:800-828,
- * src/eval_key_switch.cu:157-177) */
-int pha_lp_moddown_finish(pha_context *ctx, size_t chain_index, uint64_t *ct, uint64_t *cx_gathered, size_t q_begin,
-                          size_t q_count, pha_stream_t stream);
+/* ct[owned] += (cx - NTT(bconv(gathered p_coeff))) * P^-1 (src/rns_bconv.cu:800-828,
+ * src/eval_key_switch.cu:157-177); p_rows_host[k] = row of special limb k in p_coeff (host array of alpha entries;
+ * NULL: row k) */
+int pha_lp_moddown_finish(pha_context *ctx, size_t chain_index, uint64_t *ct, uint64_t *cx, const uint64_t *p_coeff_gathered,
+                          size_t p_coeff_poly_stride_limbs, const uint32_t *p_rows_host, size_t q_begin, size_t q_count,
+                          pha_stream_t stream);
+/* tensor_prod_2x2 / tensor_square_2x2 (src/polymath.cu:468-537) on the owned limbs [q_begin, q_begin + q_count) of
+ * operands [2][coeff_modulus_size][N]; result [3][coeff_modulus_size][N]; operand1 == operand2 squares */
+int pha_lp_tensor_prod_2x2(pha_context *ctx, const uint64_t *operand1, const uint64_t *operand2, size_t coeff_modulus_size,
+                           size_t q_begin, size_t q_count, uint64_t *result, pha_stream_t stream);
 /* owner of the last limb: last_coeff[p][N] = INTT(src[p][l-1]); broadcast it, then every rank
  * finishes its owned limbs of dst[cipher_size][l-1][N] (src/rns.cu:1157-1181) */
 int pha_lp_rescale_begin(pha_context *ctx, size_t chain_index, const uint64_t *src, size_t cipher_size,

@@ -107,8 +107,9 @@ SIGNATURES = {
     "pha_lp_modup_begin": (_int, [_vp, _sz, _vp, _vp, _sz, _sz, _vp]),
     "pha_lp_modup_finish": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "pha_lp_key_switch_inner_prod": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
-    "pha_lp_moddown_begin": (_int, [_vp, _sz, _vp, _sz, _sz, _vp]),
-    "pha_lp_moddown_finish": (_int, [_vp, _sz, _vp, _vp, _sz, _sz, _vp]),
+    "pha_lp_moddown_begin": (_int, [_vp, _sz, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "pha_lp_moddown_finish": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32), _sz, _sz, _vp]),
+    "pha_lp_tensor_prod_2x2": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     "pha_lp_rescale_begin": (_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "pha_lp_rescale_finish": (_int, [_vp, _sz, _vp, _vp, _sz, _vp, _sz, _sz, _vp]),
 }
@@ -551,11 +552,20 @@ class PhantomContext:
         _check(lib().pha_lp_key_switch_inner_prod(self._h, chain_index, _ptr(cx), _ptr(t_mod_up), evk.ptr, w[0], w[1],
                                                   w[2], w[3], _stream()))
 
-    def lp_moddown_begin(self, chain_index, cx, w):
-        _check(lib().pha_lp_moddown_begin(self._h, chain_index, _ptr(cx), w[2], w[3], _stream()))
+    def lp_moddown_begin(self, chain_index, cx, p_coeff, w, row_begin=None):
+        """p_coeff [2][rows][N]: owned P limb w[2] + j of poly z lands on p_coeff[z, row_begin + j] (default: its own index)"""
+        _check(lib().pha_lp_moddown_begin(self._h, chain_index, _ptr(cx), _ptr(p_coeff), p_coeff.shape[1],
+                                          w[2] if row_begin is None else row_begin, w[2], w[3], _stream()))
 
-    def lp_moddown_finish(self, chain_index, ct, cx, w):
-        _check(lib().pha_lp_moddown_finish(self._h, chain_index, _ptr(ct), _ptr(cx), w[0], w[1], _stream()))
+    def lp_moddown_finish(self, chain_index, ct, cx, p_coeff, w, p_rows=None):
+        """p_rows[k] = row of special limb k in p_coeff (default: k)"""
+        rows = None if p_rows is None else (ctypes.c_uint32 * len(p_rows))(*p_rows)
+        _check(lib().pha_lp_moddown_finish(self._h, chain_index, _ptr(ct), _ptr(cx), _ptr(p_coeff), p_coeff.shape[1], rows,
+                                           w[0], w[1], _stream()))
+
+    def lp_tensor_prod_2x2(self, op1, op2, result, w):
+        """result [3][l][N] = op1 [2][l][N] (x) op2 [2][l][N] on the limbs [w[0], w[0] + w[1])"""
+        _check(lib().pha_lp_tensor_prod_2x2(self._h, _ptr(op1), _ptr(op2), op1.shape[1], w[0], w[1], _ptr(result), _stream()))
 
     def lp_rescale_begin(self, chain_index, src, cipher_size, last_coeff):
         _check(lib().pha_lp_rescale_begin(self._h, chain_index, _ptr(src), cipher_size, _ptr(last_coeff), _stream()))

@@ -860,33 +860,50 @@ int lp_inner_prod(pha_context *ctx, LevelTool *lt, uint64_t *cx, const uint64_t 
     return PHA_OK;
 }
 
-int lp_moddown_begin(pha_context *ctx, LevelTool *lt, uint64_t *cx, const LimbWindow &w, hipStream_t st) {
+// INTT (+ bconv phase 1) of the owned P limbs of cx, both polys, written to p_coeff[poly][p][n] (P limb p at row p,
+// polys p_stride words apart): the buffer the ranks all-gather before the P -> Q_l conversion
+int lp_moddown_begin(pha_context *ctx, LevelTool *lt, const uint64_t *cx, uint64_t *p_coeff, size_t p_stride, size_t row_begin,
+                     const LimbWindow &w, hipStream_t st) {
     if (!w.pc) return PHA_OK;
     const size_t n = ctx->n, size_Ql = lt->size_Ql, size_QlP = size_Ql + ctx->size_P;
     NttRange rp;
     PHA_TRY(make_p_window(ctx, lt, w, rp));
     Epilogue ep{};
-    if (ctx->size_P == 1) return ntt_backward(ctx, cx, cx, 2, size_QlP * n, rp, EPI_NONE, ep, st);
+    // buffer limb size_Ql + p0 + j -> row row_begin + j; the pointer moves up when the rows start beyond the limb index
+    const size_t first = size_Ql + w.p0;
+    uint64_t *out = p_coeff;
+    size_t limb0 = first - row_begin;
+    if (row_begin > first) {
+        out = p_coeff + (row_begin - first) * n;
+        limb0 = 0;
+    }
+    if (ctx->size_P == 1) return ntt_backward(ctx, out, cx, 2, size_QlP * n, rp, EPI_NONE, ep, st, 3, limb0, p_stride);
     ep.cst = lt->PHatInv.v.p;
     ep.cst_shoup = lt->PHatInv.s.p;
     ep.cst_limb0 = static_cast<uint32_t>(size_Ql);
-    return ntt_backward(ctx, cx, cx, 2, size_QlP * n, rp, EPI_SCALE, ep, st);
+    return ntt_backward(ctx, out, cx, 2, size_QlP * n, rp, EPI_SCALE, ep, st, 3, limb0, p_stride);
 }
 
-int lp_moddown_finish(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *cx, const LimbWindow &w, hipStream_t st) {
+// ct[owned] += (cx - NTT(P -> Q_l conversion of the gathered p_coeff)) * P^-1
+int lp_moddown_finish(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *cx, const uint64_t *p_coeff, size_t p_stride,
+                      const uint32_t *p_rows, const LimbWindow &w, hipStream_t st) {
     if (!w.qc) return PHA_OK;
     const size_t n = ctx->n, size_Ql = lt->size_Ql, alpha = ctx->size_P, size_QlP = size_Ql + alpha;
     uint64_t *delta;
     PHA_TRY(ensure_workspace(ctx, 2 * size_Ql * n, &delta));
-    uint64_t *cp = cx + size_Ql * n;
     if (alpha == 1) {
-        hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(static_cast<uint32_t>(n / 512), 2u), dim3(256), 0, st, delta, cp,
-                           ctx->d_mod.p, static_cast<uint32_t>(w.q0), static_cast<uint32_t>(w.q0 + w.qc),
-                           static_cast<uint32_t>(n), size_Ql * n, size_QlP * n);
+        hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(static_cast<uint32_t>(n / 512), 2u), dim3(256), 0, st, delta,
+                           p_coeff + (p_rows ? p_rows[0] : 0) * n, ctx->d_mod.p, static_cast<uint32_t>(w.q0),
+                           static_cast<uint32_t>(w.q0 + w.qc), static_cast<uint32_t>(n), size_Ql * n, p_stride);
         PHA_TRY(check_launch("reduce_single_limb"));
     } else {
-        BconvBatch bt{size_Ql * n, size_QlP * n, 0, 0, 0, nullptr, 0, 0, 0, 0};
-        PHA_TRY(launch_bconv(ctx, delta + w.q0 * n, cp, lt->moddown_matrix.p + w.q0 * alpha, lt->moddown_obase_tidx.p + w.q0,
+        BconvBatch bt{size_Ql * n, p_stride, 0, 0, 0, nullptr, 0, 0, 0, 0};
+        if (p_rows) {
+            if (alpha > 16) return fail(PHA_ERR_INVALID_ARGUMENT, "a permuted p_coeff needs at most 16 special primes");
+            bt.in_rows_set = 1;
+            for (size_t k = 0; k < alpha; k++) bt.in_row[k] = p_rows[k];
+        }
+        PHA_TRY(launch_bconv(ctx, delta + w.q0 * n, p_coeff, lt->moddown_matrix.p + w.q0 * alpha, lt->moddown_obase_tidx.p + w.q0,
                              static_cast<uint32_t>(alpha), static_cast<uint32_t>(w.qc), static_cast<uint32_t>(w.qc), 0, 2,
                              bt, st));
     }
@@ -1545,18 +1562,42 @@ int pha_lp_key_switch_inner_prod(pha_context *ctx, size_t chain_index, uint64_t 
     return lp_inner_prod(ctx, lt, p_cx, p_t_mod_up, rlk, w, as_stream(stream));
 }
 
-int pha_lp_moddown_begin(pha_context *ctx, size_t chain_index, uint64_t *cx, size_t p_begin, size_t p_count,
-                         pha_stream_t stream) {
+int pha_lp_moddown_begin(pha_context *ctx, size_t chain_index, const uint64_t *cx, uint64_t *p_coeff, size_t p_coeff_poly_stride_limbs,
+                         size_t row_begin, size_t p_begin, size_t p_count, pha_stream_t stream) {
     const size_t q_begin = 0, q_count = 0;
-    LP_PROLOGUE(cx);
-    return lp_moddown_begin(ctx, lt, cx, w, as_stream(stream));
+    LP_PROLOGUE(cx && p_coeff);
+    if (row_begin + p_count > p_coeff_poly_stride_limbs) return fail(PHA_ERR_INVALID_ARGUMENT, "rows exceed p_coeff");
+    return lp_moddown_begin(ctx, lt, cx, p_coeff, p_coeff_poly_stride_limbs * ctx->n, row_begin, w, as_stream(stream));
 }
 
-int pha_lp_moddown_finish(pha_context *ctx, size_t chain_index, uint64_t *ct, uint64_t *cx, size_t q_begin, size_t q_count,
+int pha_lp_moddown_finish(pha_context *ctx, size_t chain_index, uint64_t *ct, uint64_t *cx, const uint64_t *p_coeff,
+                          size_t p_coeff_poly_stride_limbs, const uint32_t *p_rows_host, size_t q_begin, size_t q_count,
                           pha_stream_t stream) {
     const size_t p_begin = 0, p_count = 0;
-    LP_PROLOGUE(ct && cx);
-    return lp_moddown_finish(ctx, lt, ct, cx, w, as_stream(stream));
+    LP_PROLOGUE(ct && cx && p_coeff);
+    if (p_coeff_poly_stride_limbs < ctx->size_P) return fail(PHA_ERR_INVALID_ARGUMENT, "p_coeff holds fewer limbs than P");
+    if (p_rows_host)
+        for (size_t k = 0; k < ctx->size_P; k++)
+            if (p_rows_host[k] >= p_coeff_poly_stride_limbs) return fail(PHA_ERR_INVALID_ARGUMENT, "p_rows exceed p_coeff");
+    return lp_moddown_finish(ctx, lt, ct, cx, p_coeff, p_coeff_poly_stride_limbs * ctx->n, p_rows_host, w, as_stream(stream));
+}
+
+int pha_lp_tensor_prod_2x2(pha_context *ctx, const uint64_t *operand1, const uint64_t *operand2, size_t coeff_mod_size,
+                           size_t q_begin, size_t q_count, uint64_t *result, pha_stream_t stream) {
+    REQUIRE_CTX(operand1 && operand2 && result);
+    if (coeff_mod_size == 0 || coeff_mod_size > ctx->size_QP || q_begin + q_count > coeff_mod_size)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "limb window exceeds the ciphertext");
+    if (!q_count) return PHA_OK;
+    const uint32_t n = static_cast<uint32_t>(ctx->n);
+    if (operand1 == operand2)
+        hipLaunchKernelGGL((tensor_prod_2x2_kernel<true>), dim3(static_cast<uint32_t>(q_count) * (n / 512)), dim3(256), 0,
+                           as_stream(stream), operand1, operand2, ctx->d_mod.p, result, n, static_cast<uint32_t>(coeff_mod_size),
+                           0u, static_cast<uint32_t>(q_begin));
+    else
+        hipLaunchKernelGGL((tensor_prod_2x2_kernel<false>), dim3(static_cast<uint32_t>(q_count) * (n / 512)), dim3(256), 0,
+                           as_stream(stream), operand1, operand2, ctx->d_mod.p, result, n, static_cast<uint32_t>(coeff_mod_size),
+                           0u, static_cast<uint32_t>(q_begin));
+    return check_launch("tensor_prod_2x2 (limb window)");
 }
 
 int pha_lp_rescale_begin(pha_context *ctx, size_t chain_index, const uint64_t *src, size_t cipher_size,

@@ -25,6 +25,10 @@ struct BconvBatch {
     // the group strides to b (dst stays linear in z)
     uint32_t group;
     size_t y_group_stride, copy_group_stride;
+    // in_rows_set != 0: input limb i is row in_row[i] of y instead of row i (a gathered buffer whose rank blocks are
+    // not in limb order: limb-parallel moddown); register-path kernels only (ibase <= 16)
+    uint32_t in_rows_set;
+    uint32_t in_row[16];
 };
 
 __device__ __forceinline__ void bconv_batch_offsets(const BconvBatch &bt, uint32_t z, uint64_t *__restrict__ &dst,
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(256) void bconv_matmul_kernel(uint64_t *__restrict_
     bconv_batch_offsets(bt, blockIdx.z, dst, y, matrix, obase_tidx, skip_start, src);
     uint64_t in[IB];
 #pragma unroll
-    for (int i = 0; i < IB; i++) in[i] = y[static_cast<size_t>(i) * n + k];
+    for (int i = 0; i < IB; i++) in[i] = y[static_cast<size_t>(bt.in_rows_set ? bt.in_row[i] : i) * n + k];
     if (src != nullptr && blockIdx.y == 0) {
 #pragma unroll
         for (int i = 0; i < IB; i++) dst[static_cast<size_t>(skip_start + i) * n + k] = src[static_cast<size_t>(i) * n + k];
@@ -410,10 +414,11 @@ __global__ __launch_bounds__(256) void apply_galois_ntt_kernel(uint64_t *dst, co
 template <bool SQUARE>
 __global__ __launch_bounds__(256) void tensor_prod_2x2_kernel(const uint64_t *op1, const uint64_t *op2,
                                                               const DModulus *mod, uint64_t *res, uint32_t n,
-                                                              uint32_t limbs, uint32_t times2 = 0) {
+                                                              uint32_t limbs, uint32_t times2 = 0, uint32_t limb0 = 0) {
     // times2: (2 d0, 2 d1, 2 d2) — the doubling of a Chebyshev product taken BEFORE any division, where it is exact
+    // limb0: first limb of the window this launch covers (limb-parallel ranks take gridDim.x / per_limb limbs from there)
     const uint32_t per_limb = n / 512;
-    const uint32_t l = blockIdx.x / per_limb;
+    const uint32_t l = limb0 + blockIdx.x / per_limb;
     const size_t id = static_cast<size_t>(l) * n + ((blockIdx.x % per_limb) * 256 + threadIdx.x) * 2;
     const size_t rc = static_cast<size_t>(limbs) * n;
     const DModulus m = mod[l];

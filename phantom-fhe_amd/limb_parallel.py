@@ -1,4 +1,4 @@
-"""Limb-parallel key switch and rescale across the GPUs of one node.
+"""Limb-parallel HMult + relinearise, rotation and rescale across the GPUs of one node.
 
 The reference is single-GPU; its key switch (src/eval_key_switch.cu:91-178) is independent per
 RNS limb everywhere except the two fast base conversions, which need every input limb of a digit
@@ -6,6 +6,7 @@ per coefficient.  With the limbs of Q_l u P partitioned over the ranks (one proc
 ``torch.distributed`` over RCCL/xGMI) that leaves exactly two exchanges per key switch and one per
 rescale:
 
+    tensor        d0, d1, d2 on the owned limbs                      (HMult only)
     modup_begin   INTT + scale of the owned Q limbs of c2
     ------------  all-gather #1: coefficient-form c2, [l][N] in total
     modup_finish  base conversion + NTT of the owned limbs of every digit
@@ -19,32 +20,37 @@ Each rank keeps buffers in the single-GPU layouts and reads/writes only its limb
 ``pha_lp_*`` and a ciphertext stays limb-sharded between operations.  Results on the owned limbs
 are bit-identical to the single-GPU path.
 
-Windows are contiguous: rank r owns Q limbs ``split(l, G, r)`` and special limbs
-``split(alpha, G, G-1-r)`` (reversed so that the ranks with one Q limb fewer take the extra P
-limb).  Messages are tiny by xGMI standards (18 MiB + 12 MiB in total at N=2^16, l=36, alpha=12),
-so one all-gather per exchange, padded to the largest window, is the right granularity.
+Windows are EQUAL contiguous blocks: rank r owns Q limbs [r*bq, (r+1)*bq) with bq = ceil(l / G) (the last blocks are
+short or empty) and the special limbs of block G-1-r (reversed, so that the ranks left without Q limbs take P limbs).
+With equal blocks an all-gather needs no packing: every rank's ``all_gather_into_tensor`` input IS block `rank` of the
+output (in place).  The gathered c2 buffer [G*bq][N] then holds limb j at row j; the gathered P buffer holds special
+limb k at row p_rows[k] = (G-1 - k // bp) * bp + k % bp (blocks in rank order, ownership reversed), and the base
+conversion of the moddown reads its inputs through that row table, so nothing is repacked on either side.
+Exchange buffers are allocated once per (level, shape) and reused.  Messages are tiny by xGMI standards (18 MiB + 12 MiB in
+total at N=2^16, l=36, alpha=12), so one all-gather per buffer, padded to the block size, is the right granularity.
 """
 import threading
 
 import torch
 
 
-def split(total, parts, index):
-    """Contiguous block partition of range(total): (begin, count) of block `index`."""
-    base, rem = divmod(total, parts)
-    return index * base + min(index, rem), base + (1 if index < rem else 0)
+def block(total, parts, index):
+    """Equal-block partition of range(total): (begin, count, block) of block `index`; block = ceil(total / parts)."""
+    b = -(-total // parts) if total else 0
+    lo = min(index * b, total)
+    return lo, min(b, total - lo), b
 
 
 def limb_window(size_ql, alpha, world, rank):
     """(q_begin, q_count, p_begin, p_count) owned by `rank` at a level with size_ql Q limbs."""
-    q0, qc = split(size_ql, world, rank)
-    p0, pc = split(alpha, world, world - 1 - rank)
+    q0, qc, _ = block(size_ql, world, rank)
+    p0, pc, _ = block(alpha, world, world - 1 - rank)
     return q0, qc, p0, pc
 
 
 class TorchDistComm:
-    """Exchange over a torch.distributed process group (backend "nccl" = RCCL on ROCm; "gloo" is
-    staged through host memory and is there for tests)."""
+    """Exchange over torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" is staged through host memory and is
+    there for tests).  `reverse` selects the group whose rank order is reversed."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -54,19 +60,26 @@ class TorchDistComm:
         self.world = dist.get_world_size(group)
         self.staged = dist.get_backend(group) == "gloo"
 
-    def all_gather(self, t):
-        send = t.cpu() if self.staged and t.is_cuda else t
-        outs = [torch.empty_like(send) for _ in range(self.world)]
-        self.dist.all_gather(outs, send.contiguous(), group=self.group)
-        return [o.to(t.device) for o in outs] if send is not t else outs
+    def all_gather_blocks(self, buf, rows):
+        """buf [world * rows][...]: this rank's block (rows [rank*rows, (rank+1)*rows)) goes to every rank; in place."""
+        if self.world == 1:
+            return
+        k = self.rank
+        if self.staged and buf.is_cuda:
+            h = buf.cpu()
+            self.dist.all_gather_into_tensor(h, h[k * rows:(k + 1) * rows].clone(), group=self.group)
+            buf.copy_(h)
+        else:
+            self.dist.all_gather_into_tensor(buf, buf[k * rows:(k + 1) * rows], group=self.group)
 
     def broadcast(self, t, src):
+        gsrc = self.dist.get_global_rank(self.group, src) if self.group else src
         if self.staged and t.is_cuda:
             h = t.cpu()
-            self.dist.broadcast(h, src=self.dist.get_global_rank(self.group, src) if self.group else src, group=self.group)
+            self.dist.broadcast(h, src=gsrc, group=self.group)
             t.copy_(h)
         else:
-            self.dist.broadcast(t, src=self.dist.get_global_rank(self.group, src) if self.group else src, group=self.group)
+            self.dist.broadcast(t, src=gsrc, group=self.group)
 
 
 class ThreadComm:
@@ -82,13 +95,15 @@ class ThreadComm:
     def __init__(self, shared, rank):
         self.shared, self.rank, self.world = shared, rank, shared.world
 
-    def all_gather(self, t):
+    def all_gather_blocks(self, buf, rows):
         s = self.shared
-        s.slots[self.rank] = t
+        k = self.rank
+        s.slots[k] = buf[k * rows:(k + 1) * rows].clone()
         s.barrier.wait()
-        outs = [x.clone() for x in s.slots]
+        for j in range(self.world):
+            if j != k:
+                buf[j * rows:(j + 1) * rows] = s.slots[j]
         s.barrier.wait()
-        return outs
 
     def broadcast(self, t, src):
         s = self.shared
@@ -108,47 +123,51 @@ class LimbParallelEvaluator:
     def __init__(self, ctx, comm):
         self.ctx, self.comm = ctx, comm
         self.rank, self.world = comm.rank, comm.world
+        self._bufs = {}
 
     def windows(self, chain_index):
         size_ql = self.ctx.size_Ql(chain_index)
         return [limb_window(size_ql, self.ctx.size_P, self.world, r) for r in range(self.world)]
 
-    def _exchange(self, views, wins):
-        """views: 2-D tensors [limbs][N] sharing the per-rank windows wins[r] = (begin, count);
-        after the call every view holds every rank's window."""
-        n = views[0].shape[-1]
-        maxc = max(c for _, c in wins)
-        if maxc == 0:
-            return
-        b, c = wins[self.rank]
-        send = torch.zeros((len(views), maxc, n), dtype=views[0].dtype, device=views[0].device)
-        for i, v in enumerate(views):
-            send[i, :c] = v[b:b + c]
-        recv = self.comm.all_gather(send)
-        for r, (rb, rc) in enumerate(wins):
-            if r == self.rank or rc == 0:
-                continue
-            for i, v in enumerate(views):
-                v[rb:rb + rc] = recv[r][i, :rc]
+    def _buffers(self, chain_index, device):
+        """Exchange and scratch buffers of a level, allocated once: c2_coeff [G*bq][N] (limb j at row j), p_coeff
+        [2][G*bp][N], t_mod_up, cx."""
+        key = (chain_index, str(device))
+        b = self._bufs.get(key)
+        if b is None:
+            ctx = self.ctx
+            size_ql, alpha, n = ctx.size_Ql(chain_index), ctx.size_P, ctx.n
+            bq, bp = block(size_ql, self.world, 0)[2], block(alpha, self.world, 0)[2]
+            mk = lambda *shape: torch.empty(shape, dtype=torch.int64, device=device)  # noqa: E731
+            p_rows = [(self.world - 1 - k // bp) * bp + k % bp for k in range(alpha)]
+            b = {"bq": bq, "bp": bp, "p_rows": p_rows, "c2_coeff": mk(self.world * bq, n), "p_coeff": mk(2, self.world * bp, n),
+                 "t_mod_up": mk(ctx.beta(chain_index), size_ql + alpha, n), "cx": mk(2, size_ql + alpha, n)}
+            self._bufs[key] = b
+        return b
 
     def keyswitch_inplace(self, chain_index, ct, c2, evk):
         """ct [2][l][N] += key switch of c2 [l][N] under evk, on the owned limbs
         (src/eval_key_switch.cu:91-178)."""
         ctx = self.ctx
-        size_ql, alpha, n = ctx.size_Ql(chain_index), ctx.size_P, ctx.n
-        wins = self.windows(chain_index)
-        w = wins[self.rank]
-        dev = ct.device
-        c2_coeff = torch.empty((size_ql, n), dtype=torch.int64, device=dev)
-        ctx.lp_modup_begin(chain_index, c2, c2_coeff, w)
-        self._exchange([c2_coeff], [(q0, qc) for q0, qc, _, _ in wins])
-        t_mod_up = torch.empty((ctx.beta(chain_index), size_ql + alpha, n), dtype=torch.int64, device=dev)
-        ctx.lp_modup_finish(chain_index, t_mod_up, c2, c2_coeff, w)
-        cx = torch.empty((2, size_ql + alpha, n), dtype=torch.int64, device=dev)
-        ctx.lp_key_switch_inner_prod(chain_index, cx, t_mod_up, evk, w)
-        ctx.lp_moddown_begin(chain_index, cx, w)
-        self._exchange([cx[0], cx[1]], [(size_ql + p0, pc) for _, _, p0, pc in wins])
-        ctx.lp_moddown_finish(chain_index, ct, cx, w)
+        w = self.windows(chain_index)[self.rank]
+        b = self._buffers(chain_index, ct.device)
+        ctx.lp_modup_begin(chain_index, c2, b["c2_coeff"], w)
+        self.comm.all_gather_blocks(b["c2_coeff"], b["bq"])
+        ctx.lp_modup_finish(chain_index, b["t_mod_up"], c2, b["c2_coeff"], w)
+        ctx.lp_key_switch_inner_prod(chain_index, b["cx"], b["t_mod_up"], evk, w)
+        ctx.lp_moddown_begin(chain_index, b["cx"], b["p_coeff"], w, row_begin=self.rank * b["bp"])
+        # the two polys' P limbs: one in-place all-gather each
+        self.comm.all_gather_blocks(b["p_coeff"][0], b["bp"])
+        self.comm.all_gather_blocks(b["p_coeff"][1], b["bp"])
+        ctx.lp_moddown_finish(chain_index, ct, b["cx"], b["p_coeff"], w, p_rows=b["p_rows"])
+
+    def multiply_and_relin(self, chain_index, ct1, ct2, evk, out3):
+        """HMult + relinearise on the owned limbs (src/evaluate.cu:229-280,553-583): out3 [3][l][N] receives the tensor
+        product, its first two polys then take the key-switched third; returns out3[:2]."""
+        w = self.windows(chain_index)[self.rank]
+        self.ctx.lp_tensor_prod_2x2(ct1, ct2, out3, w)
+        self.keyswitch_inplace(chain_index, out3[:2], out3[2], evk)
+        return out3[:2]
 
     def apply_galois_inplace(self, chain_index, ct, galois_elt, galois_key):
         """Rotation on the owned limbs (src/evaluate.cu:747-794): permute c0, c1 in the NTT
@@ -181,7 +200,11 @@ class LimbParallelEvaluator:
         """All-gather the owned Q windows of the given [limbs][N] polys so that every rank holds
         them whole (hand-off to a single-GPU consumer, tests).  size_ql: limb count of `polys` if
         it differs from the level's (after a rescale the partition is still the source level's)."""
-        wins = self.windows(chain_index)
+        full = self.ctx.size_Ql(chain_index)
+        bq = block(full, self.world, 0)[2]
         limit = polys[0].shape[0] if size_ql is None else size_ql
-        clipped = [(min(q0, limit), max(0, min(q0 + qc, limit) - min(q0, limit))) for q0, qc, _, _ in wins]
-        self._exchange(list(polys), clipped)
+        for pl in polys:
+            pad = torch.zeros((self.world * bq, pl.shape[-1]), dtype=pl.dtype, device=pl.device)
+            pad[:limit] = pl[:limit]
+            self.comm.all_gather_blocks(pad, bq)
+            pl[:limit] = pad[:limit]

@@ -52,6 +52,24 @@ def test_world_size_2_gloo(tmp_path):
     assert abs(res["value"] - 64 / res["elapsed"]) < 1e-6
 
 
+def test_bench_gpus_flag_launches_ranks():
+    """`bench.py --gpus 2` with no launcher environment must start two ranks itself (a child torch.distributed.run)
+    and relay ONE JSON line whose n_gpus is the number of ranks that took part (gloo rehearsal, no GPU work)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--dry-run", "--backend", "gloo"], capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["config"]["rank0_units_of_64"] == 32
+    # one rank: no child process, same line shape
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0",
+                          "--dry-run"], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 1
+
+
 def test_limb_windows_tile_the_basis():
     sys.path.insert(0, ROOT)
     from phantom_fhe_amd.limb_parallel import limb_window
@@ -60,8 +78,10 @@ def test_limb_windows_tile_the_basis():
             wins = [limb_window(size_ql, alpha, world, r) for r in range(world)]
             assert sorted(l for q0, qc, _, _ in wins for l in range(q0, q0 + qc)) == list(range(size_ql))
             assert sorted(l for _, _, p0, pc in wins for l in range(p0, p0 + pc)) == list(range(alpha))
-            load = [qc + pc for _, qc, _, pc in wins]
-            assert max(load) - min(load) <= 1 or (size_ql % world == 0 or alpha % world == 0)
+            # equal blocks: every window but the last non-empty one has the block size, so an all-gather lands in place
+            bq = -(-size_ql // world)
+            assert all(qc == bq or q0 + qc == size_ql for q0, qc, _, _ in wins)
+            assert all(q0 == min(r * bq, size_ql) for r, (q0, _, _, _) in enumerate(wins))
 
 
 def test_limb_parallel_exchange_world_size_2_gloo(tmp_path):
@@ -83,18 +103,22 @@ def test_limb_parallel_exchange_world_size_2_gloo(tmp_path):
             def size_Ql(self, chain_index): return 6 - chain_index
         ev = LimbParallelEvaluator(Ctx(), comm)
         wins = ev.windows(1)
-        full = torch.arange(2 * 8 * 8, dtype=torch.int64).reshape(2, 8, 8) + 1   # [poly][limb][N]
-        mine = torch.zeros_like(full)
+        assert wins == [(0, 3, 2, 1), (3, 2, 0, 2)]                   # equal blocks: bq = 3, bp = 2, P reversed
+        full = torch.arange(6 * 8, dtype=torch.int64).reshape(6, 8) + 1    # padded to world * bq = 6 rows
         q0, qc, p0, pc = wins[comm.rank]
-        mine[:, q0:q0 + qc] = full[:, q0:q0 + qc]
-        mine[:, 5 + p0:5 + p0 + pc] = full[:, 5 + p0:5 + p0 + pc]
-        ev._exchange([mine[0], mine[1]], [(a, b) for a, b, _, _ in wins])            # ragged Q windows (3 + 2)
-        assert torch.equal(mine[:, :5], full[:, :5]) and (mine[:, 5:] == 0).sum() > 0
-        ev._exchange([mine[0], mine[1]], [(5 + c, d) for _, _, c, d in wins])        # ragged P windows (1 + 2)
-        assert torch.equal(mine, full)
-        last = full[0, 4].clone() if comm.rank == 0 else torch.zeros(8, dtype=torch.int64)
+        mine = torch.zeros_like(full)
+        mine[q0:q0 + qc] = full[q0:q0 + qc]
+        comm.all_gather_blocks(mine, 3)                                # in place, ragged last block (3 + 2)
+        assert torch.equal(mine[:5], full[:5])
+        plimbs = torch.arange(3 * 8, dtype=torch.int64).reshape(3, 8) + 100 # the three special limbs
+        pm = torch.zeros(4, 8, dtype=torch.int64)                           # world * bp = 4 rows, blocks in rank order
+        pm[comm.rank * 2:comm.rank * 2 + pc] = plimbs[p0:p0 + pc]           # what lp_moddown_begin(row_begin=rank*bp) does
+        comm.all_gather_blocks(pm, 2)
+        p_rows = [(2 - 1 - k // 2) * 2 + k % 2 for k in range(3)]           # the row table lp_moddown_finish reads by
+        assert p_rows == [2, 3, 0] and torch.equal(pm[p_rows], plimbs)
+        last = full[4].clone() if comm.rank == 0 else torch.zeros(8, dtype=torch.int64)
         comm.broadcast(last, 0)
-        assert torch.equal(last, full[0, 4])
+        assert torch.equal(last, full[4])
         dist.barrier()
         dist.destroy_process_group()
         print("ok", comm.rank)

@@ -70,6 +70,10 @@ def test_keyswitch_rotation_rescale(gpu, pha, orc, world, size_p, chain_index):
     exp_rot = np.stack([o.apply_galois_ntt(ct[0], elt), np.zeros_like(rot_c1)])
     o.keyswitch_inplace(size_ql, exp_rot, rot_c1, evk_h)
     exp_rs = o.divide_and_round_q_last_ntt(size_ql, ct, 2) if size_ql > 1 else None
+    ct_b = np.stack([o.uniform_poly(lim, 41), o.uniform_poly(lim, 42)])
+    d3 = o.tensor_prod_2x2(ct, ct_b)                    # HMult + relinearise, end to end (BASELINE configs[2])
+    exp_mul = d3[:2].copy()
+    o.keyswitch_inplace(size_ql, exp_mul, d3[2], evk_h)
 
     # the windows tile Q_l and P exactly
     wins = [limb_window(size_ql, size_p, world, r) for r in range(world)]
@@ -87,6 +91,11 @@ def test_keyswitch_rotation_rescale(gpu, pha, orc, world, size_p, chain_index):
         out["ks_owned"] = pha.to_host(d_ct)[:, q0:q0 + qc].copy()
         ev.gather_limbs(chain_index, [d_ct[0], d_ct[1]])
         out["ks_full"] = pha.to_host(d_ct)
+
+        d_out3 = pha.to_device(np.full((3, size_ql, N), POISON, dtype=np.uint64))
+        prod = ev.multiply_and_relin(chain_index, pha.to_device(_owned_only(ct, q0, qc, 1)),
+                                     pha.to_device(_owned_only(ct_b, q0, qc, 1)), evk, d_out3)
+        out["mul_owned"] = pha.to_host(prod)[:, q0:q0 + qc].copy()
 
         d_rot = pha.to_device(_owned_only(ct, q0, qc, 1))
         ev.apply_galois_inplace(chain_index, d_rot, elt, evk)
@@ -107,6 +116,7 @@ def test_keyswitch_rotation_rescale(gpu, pha, orc, world, size_p, chain_index):
         assert (res["ks_owned"] == exp_ks[:, q0:q0 + qc]).all(), f"rank {rank} key switch"
         assert (res["ks_full"] == exp_ks).all(), f"rank {rank} gathered key switch"
         assert (res["rot_owned"] == exp_rot[:, q0:q0 + qc]).all(), f"rank {rank} rotation"
+        assert (res["mul_owned"] == exp_mul[:, q0:q0 + qc]).all(), f"rank {rank} HMult + relinearise"
         if exp_rs is not None:
             assert (res["rs_full"] == exp_rs).all(), f"rank {rank} rescale"
 
@@ -116,10 +126,10 @@ def test_window_validation(gpu, pha, orc):
     ctx = pha.PhantomContext(LOG_N, mods, 2)
     d = pha.to_device(np.zeros((2, 6, N), dtype=np.uint64))
     with pytest.raises(pha.PhantomError) as e:
-        ctx.lp_moddown_finish(1, d, d, (3, 2, 0, 0))  # Q window [3,5) exceeds the 4 Q limbs
+        ctx.lp_moddown_finish(1, d, d, d, (3, 2, 0, 0))  # Q window [3,5) exceeds the 4 Q limbs
     assert e.value.code == pha.PHA_ERR_INVALID_ARGUMENT
     with pytest.raises(pha.PhantomError):
-        ctx.lp_moddown_begin(1, d, (0, 0, 1, 2))  # P window [1,3) exceeds alpha = 2
+        ctx.lp_moddown_begin(1, d, d, (0, 0, 1, 2))  # P window [1,3) exceeds alpha = 2
     ctx.close()
 
 

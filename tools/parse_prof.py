@@ -64,6 +64,13 @@ for name, f_kb in fetch.items():
     summary["kernels"][key] = {"kernel": name.split("(")[0], "FETCH_SIZE_raw_KB": f_kb, "WRITE_SIZE_raw_KB": w_kb,
                                "read_bytes_corrected": rb, "write_bytes_corrected": wb, "hbm_bytes_per_launch": rb + wb}
     latest[key] = rb + wb
+# stamp both files with what they were measured on: bench.py reports `traffic` only when the hash of csrc/ matches
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+head = os.popen(f"git -C {ROOT} rev-parse --short HEAD 2>/dev/null").read().strip()
+for d in (summary, latest):
+    d["source_hash"] = bench.kernel_source_hash()
+    d["git_head_at_parse"] = head
 json.dump(summary, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 json.dump(latest, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
