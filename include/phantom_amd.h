@@ -161,6 +161,11 @@ int pha_tensor_prod_2x2(pha_context *ctx, const uint64_t *operand1, const uint64
                         uint64_t *result, pha_stream_t stream);
 int pha_tensor_square_2x2(pha_context *ctx, const uint64_t *operand, size_t coeff_mod_size, uint64_t *result,
                           pha_stream_t stream);
+/* tensor_prod_mxn_rns_poly (src/polymath.cu:551-599), what multiply_internal runs for operands that are not both of
+ * size 2 (src/evaluate.cu:270-275): result[op1_size + op2_size - 1][limbs][N], result[j] = sum_{a+b=j} op1[a] * op2[b].
+ * result may alias operand1 (the reference multiplies in place).  Sizes 1..4 each. */
+int pha_tensor_prod_mxn(pha_context *ctx, const uint64_t *operand1, size_t op1_size, const uint64_t *operand2, size_t op2_size,
+                        size_t coeff_mod_size, uint64_t *result, pha_stream_t stream);
 
 /* ---- evaluator composites the host keeps (include/evaluate.cuh:114-294) ------------------ */
 /* multiply_internal + relinearize_inplace (src/evaluate.cu:229-280,553-583): ct1[2][l][N] *= ct2,

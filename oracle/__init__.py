@@ -70,6 +70,7 @@ def lib():
             "orc_apply_galois_coeff": (None, [_vp, _u64p, _sz, _u32, _u64p]),
             "orc_tensor_prod_2x2": (None, [_vp, _u64p, _u64p, _sz, _u64p]),
             "orc_tensor_square_2x2": (None, [_vp, _u64p, _sz, _u64p]),
+            "orc_tensor_prod_mxn": (None, [_vp, _u64p, _sz, _u64p, _sz, _sz, _u64p]),
             "orc_pointwise_mul": (None, [_vp, _u64p, _u64p, _u64p, _sz, ctypes.POINTER(_sz)]),
             "orc_rnd_at": (_u64, [_u64, _u64]),
             "orc_sample_ternary": (None, [_vp, _u64p, _sz, ctypes.POINTER(_sz), _u64]),
@@ -253,6 +254,14 @@ class Oracle:
         limbs = op1.shape[1]
         res = np.zeros((3, limbs, self.n), dtype=np.uint64)
         lib().orc_tensor_prod_2x2(self._h, p(np.ascontiguousarray(op1)), p(np.ascontiguousarray(op2)), limbs, p(res))
+        return res
+
+    def tensor_prod_mxn(self, op1, op2):
+        """op1 [m][limbs][n], op2 [nn][limbs][n] -> [m + nn - 1][limbs][n] (src/polymath.cu:551-599)"""
+        op1, op2 = np.ascontiguousarray(op1), np.ascontiguousarray(op2)
+        limbs = op1.shape[1]
+        res = np.zeros((op1.shape[0] + op2.shape[0] - 1, limbs, self.n), dtype=np.uint64)
+        lib().orc_tensor_prod_mxn(self._h, p(op1), op1.shape[0], p(op2), op2.shape[0], limbs, p(res))
         return res
 
     def rotate_hoisted(self, size_ql, ct, elts, evks):

@@ -664,6 +664,29 @@ void orc_tensor_square_2x2(const orc_ctx *c, const uint64_t *op, size_t limbs, u
     orc_tensor_prod_2x2(c, op, op, limbs, res);
 }
 
+/* general product (src/polymath.cu:551-599): res[j] = sum_{a+b=j} op1[a] * op2[b]; res may alias op1 (every input of a
+ * coefficient is read before its outputs are written, as in the reference) */
+void orc_tensor_prod_mxn(const orc_ctx *c, const uint64_t *op1, size_t m, const uint64_t *op2, size_t nn, size_t limbs,
+                         uint64_t *res) {
+    const size_t n = c->n, rc = limbs * n;
+    uint64_t c1[16], c2[16];
+    if (m > 16 || nn > 16) return;
+    for (size_t l = 0; l < limbs; l++) {
+        const uint64_t q = c->q[l];
+        for (size_t k = 0; k < n; k++) {
+            const size_t id = l * n + k;
+            for (size_t i = 0; i < m; i++) c1[i] = op1[id + rc * i];
+            for (size_t i = 0; i < nn; i++) c2[i] = op2[id + rc * i];
+            for (size_t j = 0; j + 1 < m + nn; j++) {
+                unsigned __int128 acc = 0;
+                for (size_t a = 0; a < m; a++)
+                    if (j >= a && j - a < nn) acc += (unsigned __int128)c1[a] * c2[j - a];
+                res[id + rc * j] = (uint64_t)(acc % q);
+            }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * helpers for tests that need *valid* keys (functional pin of the key switch):
  * evk digit d = (b_d, a_d), b_d = -a_d*s + e + [P mod q_j * s'] on the digit's own limbs

@@ -81,6 +81,8 @@ void orc_apply_galois_coeff(const orc_ctx *c, const uint64_t *operand, size_t co
 /* tensor products */
 void orc_tensor_prod_2x2(const orc_ctx *c, const uint64_t *op1, const uint64_t *op2, size_t limbs, uint64_t *res);
 void orc_tensor_square_2x2(const orc_ctx *c, const uint64_t *op, size_t limbs, uint64_t *res);
+void orc_tensor_prod_mxn(const orc_ctx *c, const uint64_t *op1, size_t m, const uint64_t *op2, size_t nn, size_t limbs,
+                         uint64_t *res);
 
 /* misc helpers for tests / fixtures */
 void orc_pointwise_mul(const orc_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t limbs,

@@ -72,6 +72,7 @@ SIGNATURES = {
     "pha_apply_galois_ntt": (_int, [_vp, _vp, _sz, _u32, _vp, _vp]),
     "pha_tensor_prod_2x2": (_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "pha_tensor_square_2x2": (_int, [_vp, _vp, _sz, _vp, _vp]),
+    "pha_tensor_prod_mxn": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp, _vp]),
     "pha_multiply_and_relin_inplace": (_int, [_vp, _sz, _vp, _vp, _vp, _vp]),
     "pha_apply_galois_inplace": (_int, [_vp, _sz, _vp, _u32, _vp, _vp]),
     "pha_rescale_to_next": (_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
@@ -346,6 +347,11 @@ class PhantomContext:
 
     def tensor_prod_2x2(self, op1, op2, coeff_mod_size, result):
         _check(lib().pha_tensor_prod_2x2(self._h, _ptr(op1), _ptr(op2), coeff_mod_size, _ptr(result), _stream()))
+
+    def tensor_prod_mxn(self, op1, op2, result):
+        """result [m + n - 1][limbs][N] from op1 [m][limbs][N], op2 [n][limbs][N]; result may alias op1"""
+        _check(lib().pha_tensor_prod_mxn(self._h, _ptr(op1), op1.shape[0], _ptr(op2), op2.shape[0], op1.shape[1], _ptr(result),
+                                         _stream()))
 
     def tensor_square_2x2(self, op, coeff_mod_size, result):
         _check(lib().pha_tensor_square_2x2(self._h, _ptr(op), coeff_mod_size, _ptr(result), _stream()))

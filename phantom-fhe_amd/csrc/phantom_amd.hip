@@ -1451,6 +1451,29 @@ int pha_tensor_prod_2x2(pha_context *ctx, const uint64_t *operand1, const uint64
     return check_launch("tensor_prod_2x2");
 }
 
+int pha_tensor_prod_mxn(pha_context *ctx, const uint64_t *operand1, size_t op1_size, const uint64_t *operand2, size_t op2_size,
+                        size_t coeff_mod_size, uint64_t *result, pha_stream_t stream) {
+    REQUIRE_CTX(operand1 && operand2 && result);
+    if (coeff_mod_size == 0 || coeff_mod_size > ctx->size_QP)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "limb range exceeds the modulus chain");
+    if (op1_size < 1 || op2_size < 1 || op1_size > 4 || op2_size > 4)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "tensor product of a size-%zu and a size-%zu ciphertext: sizes 1..4 are supported",
+                    op1_size, op2_size);
+    const uint32_t n = static_cast<uint32_t>(ctx->n), limbs = static_cast<uint32_t>(coeff_mod_size);
+    const dim3 grid(limbs * (n / 256));
+    hipStream_t st = as_stream(stream);
+#define MXN_CASE(M, NN)                                                                                                       \
+    if (op1_size == M && op2_size == NN) {                                                                                    \
+        hipLaunchKernelGGL((tensor_prod_mxn_kernel<M, NN>), grid, dim3(256), 0, st, operand1, operand2, ctx->d_mod.p, result, n, \
+                           limbs);                                                                                            \
+        return check_launch("tensor_prod_mxn");                                                                               \
+    }
+    MXN_CASE(1, 1) MXN_CASE(1, 2) MXN_CASE(1, 3) MXN_CASE(1, 4) MXN_CASE(2, 1) MXN_CASE(2, 2) MXN_CASE(2, 3) MXN_CASE(2, 4)
+    MXN_CASE(3, 1) MXN_CASE(3, 2) MXN_CASE(3, 3) MXN_CASE(3, 4) MXN_CASE(4, 1) MXN_CASE(4, 2) MXN_CASE(4, 3) MXN_CASE(4, 4)
+#undef MXN_CASE
+    return fail(PHA_ERR_LOGIC, "unreachable");
+}
+
 int pha_tensor_square_2x2(pha_context *ctx, const uint64_t *operand, size_t coeff_mod_size, uint64_t *result,
                           pha_stream_t stream) {
     REQUIRE_CTX(operand && result);

@@ -447,4 +447,33 @@ __global__ __launch_bounds__(256) void tensor_prod_2x2_kernel(const uint64_t *op
     *reinterpret_cast<ulonglong2 *>(res + id + 2 * rc) = d2;
 }
 
+// General ciphertext product (src/polymath.cu:551-599): res[j] = sum_{a + b = j} op1[a] * op2[b], every sum accumulated
+// in 128 bits and reduced once.  The M + N input words of a coefficient are read before its M + N - 1 outputs are
+// written, so res may alias op1 as in the reference's multiply_internal (src/evaluate.cu:270-275).  Operand sizes are
+// template parameters so that the inputs stay in registers (the reference allocates them with device-side new).
+template <int M, int NN>
+__global__ __launch_bounds__(256) void tensor_prod_mxn_kernel(const uint64_t *op1, const uint64_t *op2, const DModulus *mod,
+                                                              uint64_t *res, uint32_t n, uint32_t limbs) {
+    const uint32_t per_limb = n / 256;
+    const uint32_t l = blockIdx.x / per_limb;
+    const size_t id = static_cast<size_t>(l) * n + (blockIdx.x % per_limb) * 256 + threadIdx.x;
+    const size_t rc = static_cast<size_t>(limbs) * n;
+    const DModulus m = mod[l];
+    uint64_t c1[M], c2[NN];
+#pragma unroll
+    for (int i = 0; i < M; i++) c1[i] = op1[id + rc * i];
+#pragma unroll
+    for (int i = 0; i < NN; i++) c2[i] = op2[id + rc * i];
+#pragma unroll
+    for (int j = 0; j < M + NN - 1; j++) {
+        u128_t acc = {0, 0};
+#pragma unroll
+        for (int a = 0; a < M; a++) {
+            const int b = j - a;
+            if (b >= 0 && b < NN) add128(acc, mul64x64(c1[a], c2[b]));
+        }
+        res[id + rc * j] = barrett128(acc, m);
+    }
+}
+
 }  // namespace pha

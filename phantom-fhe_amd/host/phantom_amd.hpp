@@ -579,13 +579,16 @@ inline void multiply_inplace(const PhantomContext &context, PhantomCiphertext &e
         throw std::invalid_argument("encrypted1 and encrypted2 must be in NTT form");
     if (encrypted1.chain_index() != encrypted2.chain_index())
         throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
-    if (encrypted1.size() != 2 || encrypted2.size() != 2)
-        throw std::invalid_argument("only size-2 ciphertexts are supported by this layer");  // mxn tensor: not on the hot path
+    const size_t size1 = encrypted1.size(), size2 = encrypted2.size(), dest_size = size1 + size2 - 1;
+    if (size1 < 1 || size2 < 1 || size1 > 4 || size2 > 4) throw std::invalid_argument("ciphertext sizes 1..4 are supported");
     const hipStream_t &s = stream_wrapper.get_stream();
     const size_t limbs = context.coeff_mod_size(encrypted1.chain_index());
     const bool square = &encrypted1 == &encrypted2;
-    encrypted1.resize(context, encrypted1.chain_index(), 3, s);
-    if (square)
+    encrypted1.resize(context, encrypted1.chain_index(), dest_size, s);
+    if (dest_size != 3)    // tensor_prod_mxn_rns_poly (src/evaluate.cu:270-275); in place like the reference
+        check(pha_tensor_prod_mxn(context.handle(), encrypted1.data(), size1, square ? encrypted1.data() : encrypted2.data(), size2,
+                                  limbs, encrypted1.data(), s));
+    else if (square)
         check(pha_tensor_square_2x2(context.handle(), encrypted1.data(), limbs, encrypted1.data(), s));
     else
         check(pha_tensor_prod_2x2(context.handle(), encrypted1.data(), encrypted2.data(), limbs, encrypted1.data(), s));

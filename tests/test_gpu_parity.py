@@ -252,6 +252,29 @@ def test_tensor_and_multiply_relin(gpu, pha, small):
     assert (_host(pha, d_ct1)[:2] == exp).all()
 
 
+@pytest.mark.parametrize("m,nn", [(3, 2), (3, 3), (2, 2), (1, 3), (4, 4)])
+def test_tensor_prod_mxn(gpu, pha, small, m, nn):
+    """tensor_prod_mxn_rns_poly (src/polymath.cu:551-599): what multiply_internal runs when an operand has more than
+    two polys; in place on operand 1 like the reference (src/evaluate.cu:270-275)."""
+    ctx, o = small
+    size_ql = 5
+    lim = list(range(size_ql))
+    a = np.stack([o.uniform_poly(lim, 300 + i) for i in range(m)])
+    b = np.stack([o.uniform_poly(lim, 320 + i) for i in range(nn)])
+    ref = o.tensor_prod_mxn(a, b)
+    if (m, nn) == (2, 2):
+        assert (ref == o.tensor_prod_2x2(a, b)).all()          # the 2x2 kernels are the same map
+    d_res = _dev(pha, np.zeros_like(ref))
+    ctx.tensor_prod_mxn(_dev(pha, a), _dev(pha, b), d_res)
+    assert (_host(pha, d_res) == ref).all()
+    # in place: the result overwrites operand 1 (buffer sized for the product)
+    d_inplace = _dev(pha, np.concatenate([a, np.zeros((nn - 1, size_ql, a.shape[-1]), dtype=np.uint64)]))
+    ctx.tensor_prod_mxn(d_inplace[:m], _dev(pha, b), d_inplace)
+    assert (_host(pha, d_inplace) == ref).all()
+    with pytest.raises(pha.PhantomError):
+        ctx.tensor_prod_mxn(_dev(pha, np.zeros((5, size_ql, a.shape[-1]), dtype=np.uint64)), _dev(pha, b), d_res)
+
+
 @pytest.mark.parametrize("size_p,chain_index", [(2, 1), (2, 3), (1, 2), (3, 1)])
 def test_double_hoisted_linear_transform(gpu, pha, orc, size_p, chain_index):
     """pha_linear_transform_double_hoisted against its restatement from the oracle's primitives (bit-exact; uniform

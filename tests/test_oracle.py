@@ -257,3 +257,20 @@ def test_tensor_product(orc):
         for k in (0, 5, n - 1):
             a0, a1, b0, b1 = (int(a[0, l, k]), int(a[1, l, k]), int(b[0, l, k]), int(b[1, l, k]))
             assert [int(r[i, l, k]) for i in range(3)] == [a0 * b0 % m, (a0 * b1 + a1 * b0) % m, a1 * b1 % m]
+
+
+def test_tensor_prod_mxn_is_the_polynomial_product_in_y(orc):
+    """(sum_a c_a y^a)(sum_b c'_b y^b) coefficient-wise: checked with Python integers; 2x2 agrees with tensor_prod_2x2"""
+    mods = orc.coeff_modulus_create(4096, [50, 45, 60])
+    o = orc.Oracle(12, mods, 1)
+    lim = [0, 1]
+    a = np.stack([o.uniform_poly(lim, 1 + i) for i in range(3)])
+    b = np.stack([o.uniform_poly(lim, 11 + i) for i in range(2)])
+    res = o.tensor_prod_mxn(a, b)
+    assert res.shape == (4, 2, 4096)
+    for l, q in enumerate(int(m) for m in mods[:2]):
+        for k in (0, 1, 777, 4095):
+            for j in range(4):
+                want = sum(int(a[x, l, k]) * int(b[j - x, l, k]) for x in range(3) if 0 <= j - x < 2) % q
+                assert int(res[j, l, k]) == want
+    assert (o.tensor_prod_mxn(a[:2], b) == o.tensor_prod_2x2(a[:2], b)).all()
