@@ -245,10 +245,19 @@ int pha_lp_rescale_finish(pha_context *ctx, size_t chain_index, const uint64_t *
 /* ---- key generation, symmetric encryption, decryption --------------------
  * PhantomSecretKey's methods (include/secretkey.h:150-290, src/secretkey.cu) over caller-owned
  * buffers.  Distributions are the reference's (src/prng.cu: ternary, centred binomial, uniform by
- * rejection); the generator is seeded and random-access (csrc/keygen_kernels.cuh) where the
- * reference seeds from std::random_device, so results are reproducible from the seeds.
+ * rejection).  Randomness is a keyed stream cipher as in the reference (Salsa20 under a std::random_device key,
+ * src/prng.cu): draw number ctr of stream `seed` is the first 64 bits of ChaCha20(key, counter/nonce = (ctr, seed)) under
+ * the PROCESS'S 256-bit sampler key, which is drawn from OS entropy on first use.  The `seed` arguments below are
+ * therefore public NONCES that name a stream under that key (distinct nonces = independent streams), not secrets:
+ * use a fresh one per draw (pha_random_nonce) and never reuse a nonce for two objects.  With the key fixed by
+ * pha_set_sampler_key (tests, the oracle) results are reproducible from the nonces.
  * chain_index 0 is the key level (all of Q u P), i >= 1 the first size_Q-(i-1) limbs of Q. */
 /* gen_secretkey (src/secretkey.cu:368-440): sk[size_QP][N], ternary, NTT form */
+/* Installs the 32-byte sampler key (NULL: 32 fresh bytes of OS entropy).  A fixed key makes every sampled object a
+ * function of its nonces: for tests and the oracle comparison only. */
+int pha_set_sampler_key(const uint8_t *key32);
+/* 64 bits of OS entropy: a nonce for one draw. */
+int pha_random_nonce(uint64_t *out);
 int pha_gen_secretkey(pha_context *ctx, uint64_t seed, uint64_t *sk, pha_stream_t stream);
 /* encrypt_zero_symmetric (src/secretkey.cu:207-263, NTT form): ct[2][l][N] = (-(a*s+e), a) */
 int pha_encrypt_zero_symmetric(pha_context *ctx, const uint64_t *sk, size_t chain_index, uint64_t seed_a,

@@ -73,6 +73,8 @@ def lib():
             "orc_tensor_prod_mxn": (None, [_vp, _u64p, _sz, _u64p, _sz, _sz, _u64p]),
             "orc_pointwise_mul": (None, [_vp, _u64p, _u64p, _u64p, _sz, ctypes.POINTER(_sz)]),
             "orc_rnd_at": (_u64, [_u64, _u64]),
+            "orc_set_sampler_key": (None, [ctypes.c_char_p]),
+            "orc_chacha20_block": (None, [ctypes.POINTER(ctypes.c_uint32), _u64, _u64, ctypes.POINTER(ctypes.c_uint32)]),
             "orc_sample_ternary": (None, [_vp, _u64p, _sz, ctypes.POINTER(_sz), _u64]),
             "orc_sample_error": (None, [_vp, _u64p, _sz, ctypes.POINTER(_sz), _u64]),
             "orc_sample_uniform": (None, [_vp, _u64p, _sz, ctypes.POINTER(_sz), _u64]),
@@ -341,6 +343,22 @@ class Oracle:
 
 def rnd_at(seed, ctr):
     return int(lib().orc_rnd_at(seed, ctr))
+
+
+SAMPLER_KEY = bytes(32)   # the oracle's fixed sampler key; tests install the same key in the library
+
+
+def set_sampler_key(key32):
+    assert len(key32) == 32
+    lib().orc_set_sampler_key(bytes(key32))
+
+
+def chacha20_block(key_words, seed, ctr):
+    """RFC 8439 block function with counter / nonce words (ctr_lo, ctr_hi, seed_lo, seed_hi): 16 output words"""
+    k = (ctypes.c_uint32 * 8)(*key_words)
+    out = (ctypes.c_uint32 * 16)()
+    lib().orc_chacha20_block(k, seed, ctr, out)
+    return list(out)
 
 
 def galois_table(log_n, elt):

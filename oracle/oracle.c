@@ -737,16 +737,39 @@ void orc_fill_uniform(uint64_t *out, size_t count, uint64_t q, uint64_t seed) {
  * generate_one_kswitch_key :265-310 + src/polymath.cu:323-343, gen_relinkey :452-477,
  * create_galois_keys :479-521, ckks_decrypt :584-624) and the samplers of src/prng.cu
  * (ternary :142-163, centred binomial :219-242, uniform by rejection :174-207).
- * Randomness is this project's own SEEDED, counter-based generator (the reference draws seeds
- * from std::random_device and expands them with a stream cipher, so its outputs are not
- * reproducible by design, and this fork's "uniform" sampler stores the constant 1,
- * src/prng.cu:201-203 — the sampler here is the uniform one the comment there describes):
- *     rnd(seed, ctr) = SplitMix64 output number ctr+1 of the stream started at `seed`
- * which is random-access, so the GPU computes every coefficient independently.
+ * Randomness: like the reference (Salsa20 under a std::random_device key, src/prng.cu:17,157,192,231) the library
+ * samples with a keyed stream cipher — draw ctr of stream `seed` is the first 64 bits of the ChaCha20 block (RFC 8439)
+ * under a 256-bit sampler key with counter / nonce words (ctr_lo, ctr_hi, seed_lo, seed_hi); `seed` is a public nonce.
+ * The library draws its key from OS entropy; the oracle, being the checker, keeps a FIXED key (all zero unless
+ * orc_set_sampler_key changes it) and the tests install the same key in the library to compare key material bit for bit.
+ * (This fork's "uniform" sampler stores the constant 1, src/prng.cu:201-203 — the sampler here is the uniform one the
+ * comment there describes.)  The generator is random-access, so the GPU computes every coefficient independently.
  * ---------------------------------------------------------------------------------------- */
+static uint32_t g_sampler_key[8];
+
+void orc_set_sampler_key(const uint8_t *key32) { memcpy(g_sampler_key, key32, 32); }
+
+#define ROTL32(x, r) (((x) << (r)) | ((x) >> (32 - (r))))
+#define QR(a, b, c, d) \
+    a += b; d ^= a; d = ROTL32(d, 16); c += d; b ^= c; b = ROTL32(b, 12); a += b; d ^= a; d = ROTL32(d, 8); c += d; b ^= c; b = ROTL32(b, 7);
+
+/* RFC 8439 section 2.3: 10 double rounds, then the input state is added */
+void orc_chacha20_block(const uint32_t key[8], uint64_t seed, uint64_t ctr, uint32_t out[16]) {
+    uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6],
+                       key[7], (uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t x[16];
+    memcpy(x, in, sizeof(x));
+    for (int r = 0; r < 10; r++) {
+        QR(x[0], x[4], x[8], x[12]) QR(x[1], x[5], x[9], x[13]) QR(x[2], x[6], x[10], x[14]) QR(x[3], x[7], x[11], x[15])
+        QR(x[0], x[5], x[10], x[15]) QR(x[1], x[6], x[11], x[12]) QR(x[2], x[7], x[8], x[13]) QR(x[3], x[4], x[9], x[14])
+    }
+    for (int i = 0; i < 16; i++) out[i] = x[i] + in[i];
+}
+
 static inline uint64_t rnd_at(uint64_t seed, uint64_t ctr) {
-    uint64_t s = seed + ctr * 0x9E3779B97F4A7C15ULL;
-    return splitmix64(&s);
+    uint32_t o[16];
+    orc_chacha20_block(g_sampler_key, seed, ctr, o);
+    return ((uint64_t)o[1] << 32) | o[0];
 }
 
 uint64_t orc_rnd_at(uint64_t seed, uint64_t ctr) { return rnd_at(seed, ctr); }

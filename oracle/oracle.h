@@ -93,6 +93,8 @@ void orc_fill_uniform(uint64_t *out, size_t count, uint64_t q, uint64_t seed);
 /* key generation / symmetric encryption / decryption with the project's seeded generator
  * (oracle.c, "Key generation"; src/secretkey.cu, src/prng.cu) */
 uint64_t orc_rnd_at(uint64_t seed, uint64_t ctr);
+void orc_set_sampler_key(const uint8_t *key32);
+void orc_chacha20_block(const uint32_t key[8], uint64_t seed, uint64_t ctr, uint32_t out[16]);
 void orc_sample_ternary(const orc_ctx *c, uint64_t *out, size_t limbs, const size_t *table_idx, uint64_t seed);
 void orc_sample_error(const orc_ctx *c, uint64_t *out, size_t limbs, const size_t *table_idx, uint64_t seed);
 void orc_sample_uniform(const orc_ctx *c, uint64_t *out, size_t limbs, const size_t *table_idx, uint64_t seed);

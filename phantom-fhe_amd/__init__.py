@@ -36,6 +36,8 @@ _intp = ctypes.POINTER(_int)
 # name -> (restype, argtypes); must cover every function declared in include/phantom_amd.h
 SIGNATURES = {
     "pha_last_error": (ctypes.c_char_p, []),
+    "pha_set_sampler_key": (_int, [ctypes.c_char_p]),
+    "pha_random_nonce": (_int, [ctypes.POINTER(ctypes.c_uint64)]),
     "pha_version": (ctypes.c_char_p, []),
     "pha_coeff_modulus_create": (_int, [_sz, _intp, _sz, _u64p]),
     "pha_host_ntt_tables": (_int, [_int, _u64, _u64p, _u64p, _u64p, _u64p, _u64p, _u64p]),
@@ -146,6 +148,22 @@ def lib():
 def _check(rc):
     if rc != PHA_OK:
         raise PhantomError(rc, lib().pha_last_error().decode())
+
+
+def set_sampler_key(key32=None):
+    """Installs the process's 256-bit sampler key (None: fresh OS entropy, the default state).  A fixed key makes
+    every sampled object a function of its nonces: tests and oracle comparisons only."""
+    if key32 is not None:
+        assert len(key32) == 32
+        key32 = bytes(key32)
+    _check(lib().pha_set_sampler_key(key32))
+
+
+def random_nonce():
+    """64 bits of OS entropy: the `seed` (nonce) of one draw"""
+    out = ctypes.c_uint64(0)
+    _check(lib().pha_random_nonce(ctypes.byref(out)))
+    return out.value
 
 
 def _np_u64(a):

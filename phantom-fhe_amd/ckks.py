@@ -144,7 +144,7 @@ class GpuEvaluator(EvaluatorBase):
     """Every primitive is a C-ABI call on `ctx` (phantom_fhe_amd.PhantomContext).  Keys are generated
     on the GPU from `sk` for the rotations announced with `add_rotation_keys`."""
 
-    def __init__(self, pha, ctx, sk, sparse_slots, seed=1000, double_hoisting=True):
+    def __init__(self, pha, ctx, sk, sparse_slots, seed=None, double_hoisting=True):
         super().__init__(ctx.log_n, ctx.moduli[:ctx.size_Q], sparse_slots)
         self.pha, self.ctx, self.sk = pha, ctx, sk
         self.double_hoisting = double_hoisting
@@ -162,6 +162,10 @@ class GpuEvaluator(EvaluatorBase):
         self.auto_keys = False               # generate a missing rotation key on first use (cnn.py: hundreds of steps)
 
     def _next_seed(self):
+        """nonce of the next draw: OS entropy, or consecutive numbers from `seed` when one was given (reproducible runs
+        under a fixed sampler key: tests)"""
+        if self._seed is None:
+            return self.pha.random_nonce()
         self._seed += 1
         return self._seed
 
@@ -360,7 +364,7 @@ class GpuEvaluator(EvaluatorBase):
             EvaluatorBase.__init__(sib, self.log_n, self.q, self.s)
             sib.pha, sib.sk, sib.rlk, sib.galois = self.pha, self.sk, self.rlk, self.galois
             sib.ctx = self.pha.PhantomContext(self.ctx.log_n, self.ctx.moduli, self.ctx.size_P)
-            sib._seed, sib._mono, sib.auto_keys = self._seed + ((len(sibs) + 1) << 20), {}, False
+            sib._seed, sib._mono, sib.auto_keys = (None if self._seed is None else self._seed + ((len(sibs) + 1) << 20)), {}, False
             sib.double_hoisting, sib.baby_bias = self.double_hoisting, self.baby_bias
             sib.merged_rescale, sib.concurrent_pairs = self.merged_rescale, self.concurrent_pairs
             sib.stream = torch.cuda.Stream()

@@ -1,20 +1,49 @@
 // Samplers and element-wise kernels of key generation, symmetric encryption and decryption
 // (SURVEY.md §8f.1).  Distributions follow src/prng.cu of the reference (ternary :142-163,
-// centred binomial :219-242, uniform by rejection :174-207); the generator is this project's
-// seeded, random-access one — rnd(seed, ctr) = output ctr+1 of the SplitMix64 stream started at
-// `seed` — so that every coefficient is computed independently and runs are reproducible (the
-// reference seeds from std::random_device).  Element-wise arithmetic restates src/polymath.cu.
+// centred binomial :219-242, uniform by rejection :174-207).  Element-wise arithmetic restates src/polymath.cu.
+//
+// Randomness: a keyed stream cipher, as in the reference (Salsa20 under a std::random_device key, src/prng.cu:17,157,192,231).
+//     rnd(key, seed, ctr) = first 64 bits of the ChaCha20 block (RFC 8439, 20 rounds) under the 256-bit `key` whose
+//                           counter / nonce words are (ctr_lo, ctr_hi, seed_lo, seed_hi)
+// `key` is the process's sampler key: 32 bytes of OS entropy drawn when the library first samples (pha_set_sampler_key
+// replaces it; tests and the oracle fix it to compare key material bit for bit).  The 64-bit `seed` arguments of the C ABI
+// are NONCES that name a stream under that key, not secrets: everything published (the uniform `a` of a ciphertext or key)
+// is ChaCha20 output, from which neither the key nor any other stream (secret key, errors, other nonces) can be derived.
+// The generator stays random-access, so every coefficient is sampled independently.
 #pragma once
 
 #include "modarith.cuh"
 
 namespace pha {
 
-__device__ __forceinline__ uint64_t rnd_at(uint64_t seed, uint64_t ctr) {
-    uint64_t z = seed + (ctr + 1) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+struct SamplerKey {
+    uint32_t w[8];
+};
+
+__host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+#define PHA_CHACHA_QR(a, b, c, d) \
+    a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); a += b; d ^= a; d = rotl32(d, 8); c += d; b ^= c; b = rotl32(b, 7);
+
+// ChaCha20 block function, first `words` (<= 16) output words
+__host__ __device__ __forceinline__ void chacha20_block(const SamplerKey &key, uint64_t seed, uint64_t ctr, uint32_t *out, int words) {
+    const uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
+                             key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7],
+                             static_cast<uint32_t>(ctr), static_cast<uint32_t>(ctr >> 32), static_cast<uint32_t>(seed),
+                             static_cast<uint32_t>(seed >> 32)};
+    uint32_t x0 = in[0], x1 = in[1], x2 = in[2], x3 = in[3], x4 = in[4], x5 = in[5], x6 = in[6], x7 = in[7], x8 = in[8],
+             x9 = in[9], x10 = in[10], x11 = in[11], x12 = in[12], x13 = in[13], x14 = in[14], x15 = in[15];
+    for (int r = 0; r < 10; r++) {
+        PHA_CHACHA_QR(x0, x4, x8, x12) PHA_CHACHA_QR(x1, x5, x9, x13) PHA_CHACHA_QR(x2, x6, x10, x14) PHA_CHACHA_QR(x3, x7, x11, x15)
+        PHA_CHACHA_QR(x0, x5, x10, x15) PHA_CHACHA_QR(x1, x6, x11, x12) PHA_CHACHA_QR(x2, x7, x8, x13) PHA_CHACHA_QR(x3, x4, x9, x14)
+    }
+    const uint32_t x[16] = {x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15};
+    for (int i = 0; i < words; i++) out[i] = x[i] + in[i];
+}
+
+__host__ __device__ __forceinline__ uint64_t rnd_at(const SamplerKey &key, uint64_t seed, uint64_t ctr) {
+    uint32_t o[2];
+    chacha20_block(key, seed, ctr, o, 2);
+    return (static_cast<uint64_t>(o[1]) << 32) | o[0];
 }
 
 enum : int { SAMPLE_TERNARY = 0, SAMPLE_ERROR = 1, SAMPLE_UNIFORM = 2 };
@@ -23,7 +52,7 @@ enum : int { SAMPLE_TERNARY = 0, SAMPLE_ERROR = 1, SAMPLE_UNIFORM = 2 };
 // for the two small distributions so that the draw is shared by every limb
 template <int KIND>
 __global__ __launch_bounds__(256) void sample_poly_kernel(uint64_t *out, const DModulus *mod, uint32_t limbs, uint32_t n,
-                                                          uint64_t seed) {
+                                                          SamplerKey key, uint64_t seed) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (KIND == SAMPLE_UNIFORM) {
         const uint32_t l = blockIdx.y;
@@ -32,10 +61,10 @@ __global__ __launch_bounds__(256) void sample_poly_kernel(uint64_t *out, const D
         // largest r accepted: 2^64 - 1 - ((2^64 - 1) mod q) - 1 (src/prng.cu:188)
         const uint64_t max_multiple = ~0ull - barrett64(~0ull, m.value, m.ratio1) - 1;
         uint64_t ctr = static_cast<uint64_t>(l) * n + k, r;
-        while ((r = rnd_at(seed, ctr)) > max_multiple) ctr += total;
+        while ((r = rnd_at(key, seed, ctr)) > max_multiple) ctr += total;
         out[static_cast<size_t>(l) * n + k] = barrett64(r, m.value, m.ratio1);
     } else {
-        const uint64_t r = rnd_at(seed, k);
+        const uint64_t r = rnd_at(key, seed, k);
         int v;
         if (KIND == SAMPLE_TERNARY)
             v = static_cast<int>((r & 0xFF) % 3) - 1;

@@ -3,6 +3,8 @@
 // product.  Host orchestration follows the dataflow of src/rns_bconv.cu, src/eval_key_switch.cu,
 // src/rns.cu:1157-1181 and src/evaluate.cu of the reference; kernels are in *_kernels.cuh.
 #include <hip/hip_runtime.h>
+#include <errno.h>
+#include <sys/random.h>
 
 #include <algorithm>
 #include <cmath>
@@ -11,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -942,11 +945,42 @@ int lp_rescale_finish(pha_context *ctx, LevelTool *lt, const uint64_t *src, cons
 }
 
 // ---- key generation / encryption / decryption -------------------------------
-uint64_t host_rnd_at(uint64_t seed, uint64_t ctr) {  // same stream as rnd_at() in keygen_kernels.cuh
-    uint64_t z = seed + (ctr + 1) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+// The process's sampler key (csrc/keygen_kernels.cuh): 32 bytes of OS entropy on first use, or what
+// pha_set_sampler_key installed.  Guarded by a mutex: contexts of several threads share it.
+std::mutex g_sampler_mutex;
+bool g_sampler_key_set = false;
+SamplerKey g_sampler_key;
+
+int os_entropy(void *buf, size_t len) {
+    uint8_t *p = static_cast<uint8_t *>(buf);
+    while (len) {
+        const ssize_t got = getrandom(p, len, 0);
+        if (got < 0) {
+            if (errno == EINTR) continue;
+            return fail(PHA_ERR_LOGIC, "getrandom failed: %s", strerror(errno));
+        }
+        p += got;
+        len -= static_cast<size_t>(got);
+    }
+    return PHA_OK;
+}
+
+int sampler_key(SamplerKey &out) {
+    std::lock_guard<std::mutex> lock(g_sampler_mutex);
+    if (!g_sampler_key_set) {
+        PHA_TRY(os_entropy(g_sampler_key.w, sizeof(g_sampler_key.w)));
+        g_sampler_key_set = true;
+    }
+    out = g_sampler_key;
+    return PHA_OK;
+}
+
+// same stream as rnd_at() on the device
+int host_rnd_at(uint64_t seed, uint64_t ctr, uint64_t &out) {
+    SamplerKey key;
+    PHA_TRY(sampler_key(key));
+    out = rnd_at(key, seed, ctr);
+    return PHA_OK;
 }
 
 // chain_index 0 = key level (all of Q u P), i >= 1 = the first size_Q-(i-1) limbs of Q
@@ -958,12 +992,14 @@ int level_limbs(const pha_context *ctx, size_t chain_index, size_t *limbs) {
 
 int launch_sample(pha_context *ctx, int kind, uint64_t *out, size_t limbs, uint64_t seed, hipStream_t st) {
     const uint32_t n = static_cast<uint32_t>(ctx->n), L = static_cast<uint32_t>(limbs);
+    SamplerKey key;
+    PHA_TRY(sampler_key(key));
     if (kind == SAMPLE_UNIFORM)
-        hipLaunchKernelGGL((sample_poly_kernel<SAMPLE_UNIFORM>), dim3(n / 256, L), dim3(256), 0, st, out, ctx->d_mod.p, L, n, seed);
+        hipLaunchKernelGGL((sample_poly_kernel<SAMPLE_UNIFORM>), dim3(n / 256, L), dim3(256), 0, st, out, ctx->d_mod.p, L, n, key, seed);
     else if (kind == SAMPLE_TERNARY)
-        hipLaunchKernelGGL((sample_poly_kernel<SAMPLE_TERNARY>), dim3(n / 256), dim3(256), 0, st, out, ctx->d_mod.p, L, n, seed);
+        hipLaunchKernelGGL((sample_poly_kernel<SAMPLE_TERNARY>), dim3(n / 256), dim3(256), 0, st, out, ctx->d_mod.p, L, n, key, seed);
     else
-        hipLaunchKernelGGL((sample_poly_kernel<SAMPLE_ERROR>), dim3(n / 256), dim3(256), 0, st, out, ctx->d_mod.p, L, n, seed);
+        hipLaunchKernelGGL((sample_poly_kernel<SAMPLE_ERROR>), dim3(n / 256), dim3(256), 0, st, out, ctx->d_mod.p, L, n, key, seed);
     return check_launch("sample_poly");
 }
 
@@ -1008,7 +1044,10 @@ int do_kswitch_key(pha_context *ctx, const uint64_t *sk, const uint64_t *new_key
     }
     for (size_t d = 0; d < dnum; d++) {
         if (!evks[d]) return fail(PHA_ERR_INVALID_ARGUMENT, "null key buffer");
-        PHA_TRY(do_encrypt_zero(ctx, sk, 0, host_rnd_at(seed, 2 * d), host_rnd_at(seed, 2 * d + 1), evks[d], st));
+        uint64_t seed_a, seed_e;
+        PHA_TRY(host_rnd_at(seed, 2 * d, seed_a));
+        PHA_TRY(host_rnd_at(seed, 2 * d + 1, seed_e));
+        PHA_TRY(do_encrypt_zero(ctx, sk, 0, seed_a, seed_e, evks[d], st));
         const size_t j0 = d * alpha;
         PHA_TRY(launch_ew(ctx, EW_MUL_CONST_ADD, evks[d] + j0 * n, new_key + j0 * n, nullptr, evks[d] + j0 * n,
                           ctx->d_bigP_mod_q.p + j0, j0, alpha, st));
@@ -1645,6 +1684,22 @@ int pha_lp_rescale_finish(pha_context *ctx, size_t chain_index, const uint64_t *
 }
 
 // ---- key generation, symmetric encryption, decryption -----------------------
+int pha_set_sampler_key(const uint8_t *key32) {
+    std::lock_guard<std::mutex> lock(g_sampler_mutex);
+    if (key32) {
+        memcpy(g_sampler_key.w, key32, sizeof(g_sampler_key.w));
+    } else {
+        PHA_TRY(os_entropy(g_sampler_key.w, sizeof(g_sampler_key.w)));
+    }
+    g_sampler_key_set = true;
+    return PHA_OK;
+}
+
+int pha_random_nonce(uint64_t *out) {
+    if (!out) return fail(PHA_ERR_INVALID_ARGUMENT, "null argument");
+    return os_entropy(out, sizeof(*out));
+}
+
 int pha_gen_secretkey(pha_context *ctx, uint64_t seed, uint64_t *sk, pha_stream_t stream) {
     REQUIRE_CTX(sk);
     hipStream_t st = as_stream(stream);
@@ -1671,7 +1726,10 @@ int pha_encrypt_symmetric(pha_context *ctx, const uint64_t *sk, const uint64_t *
 
 int pha_gen_publickey(pha_context *ctx, const uint64_t *sk, uint64_t seed, uint64_t *pk, pha_stream_t stream) {
     REQUIRE_CTX(sk && pk);
-    return do_encrypt_zero(ctx, sk, 0, host_rnd_at(seed, 0), host_rnd_at(seed, 1), pk, as_stream(stream));
+    uint64_t seed_a, seed_e;
+    PHA_TRY(host_rnd_at(seed, 0, seed_a));
+    PHA_TRY(host_rnd_at(seed, 1, seed_e));
+    return do_encrypt_zero(ctx, sk, 0, seed_a, seed_e, pk, as_stream(stream));
 }
 
 int pha_encrypt_zero_asymmetric(pha_context *ctx, const uint64_t *pk, size_t chain_index, uint64_t seed, uint64_t *ct,
@@ -1691,9 +1749,11 @@ int pha_encrypt_zero_asymmetric(pha_context *ctx, const uint64_t *pk, size_t cha
     uint64_t *u = ws, *cx = u + QP * n, *delta = cx + 2 * QP * n, *top = delta + 2 * Q * n;
     NttRange r;
     PHA_TRY(make_range(ctx, QP, 0, 0, 0, 0, 0, r));
-    PHA_TRY(launch_sample(ctx, SAMPLE_TERNARY, u, QP, host_rnd_at(seed, 0), st));
+    uint64_t sub[3];
+    for (uint64_t i = 0; i < 3; i++) PHA_TRY(host_rnd_at(seed, i, sub[i]));
+    PHA_TRY(launch_sample(ctx, SAMPLE_TERNARY, u, QP, sub[0], st));
     PHA_TRY(ntt_forward(ctx, u, 1, 0, r, EPI_NONE, Epilogue{}, st));
-    for (size_t i = 0; i < 2; i++) PHA_TRY(launch_sample(ctx, SAMPLE_ERROR, cx + i * QP * n, QP, host_rnd_at(seed, 1 + i), st));
+    for (size_t i = 0; i < 2; i++) PHA_TRY(launch_sample(ctx, SAMPLE_ERROR, cx + i * QP * n, QP, sub[1 + i], st));
     PHA_TRY(ntt_forward(ctx, cx, 2, QP * n, r, EPI_NONE, Epilogue{}, st));
     for (size_t i = 0; i < 2; i++)   // cx_i = u * pk_i + e_i
         PHA_TRY(launch_ew(ctx, EW_MUL_ADD, cx + i * QP * n, u, pk + i * QP * n, cx + i * QP * n, nullptr, 0, QP, st));
@@ -2235,9 +2295,12 @@ int pha_gen_secretkey_sparse(pha_context *ctx, uint64_t seed, size_t hamming_wei
     for (size_t i = 0; i < n; i++) pos[i] = static_cast<uint32_t>(i);
     std::vector<uint64_t> h(L * n, 0);
     for (size_t i = 0; i < hamming_weight; i++) {  // partial Fisher-Yates
-        const size_t j = i + static_cast<size_t>(host_rnd_at(seed, 2 * i) % (n - i));
+        uint64_t r_pos, r_sign;
+        PHA_TRY(host_rnd_at(seed, 2 * i, r_pos));
+        PHA_TRY(host_rnd_at(seed, 2 * i + 1, r_sign));
+        const size_t j = i + static_cast<size_t>(r_pos % (n - i));
         std::swap(pos[i], pos[j]);
-        const bool minus = host_rnd_at(seed, 2 * i + 1) & 1;
+        const bool minus = r_sign & 1;
         for (size_t l = 0; l < L; l++) h[l * n + pos[i]] = minus ? ctx->moduli[l] - 1 : 1;
     }
     hipStream_t st = as_stream(stream);

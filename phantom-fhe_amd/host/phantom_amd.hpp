@@ -420,38 +420,37 @@ public:
 class PhantomPublicKey {
     friend class PhantomSecretKey;
     device_words pk_;  // [2][size_QP][N], NTT form: an encryption of zero at the key level
-    uint64_t seed_ = 0, draws_ = 0;
 
 public:
     PhantomPublicKey() = default;
     PhantomPublicKey(PhantomPublicKey &&) = default;
     PhantomPublicKey &operator=(PhantomPublicKey &&) = default;
     uint64_t *data() const { return pk_.get(); }
-    // src/secretkey.cu:133-164: fresh randomness per call (u, e0, e1), derived from the key's construction seed
+    // src/secretkey.cu:133-164: fresh randomness per call (u, e0, e1)
     void encrypt_asymmetric(const PhantomContext &context, const PhantomPlaintext &plain, PhantomCiphertext &cipher,
                             const hip_stream_wrapper &sw = default_stream()) {
         if (!pk_.get()) throw std::logic_error("public key has not been generated");
         const hipStream_t &s = sw.get_stream();
         cipher.resize(context, plain.chain_index(), 2, s);
-        uint64_t z = seed_ + (++draws_) * 0x9E3779B97F4A7C15ULL;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-        check(pha_encrypt_asymmetric(context.handle(), pk_.get(), plain.data(), plain.chain_index(), z ^ (z >> 31), cipher.data(), s));
+        uint64_t nonce;   // nothing derived from the key owner's state lives in the public object: a fresh OS-entropy nonce per call
+        check(pha_random_nonce(&nonce));
+        check(pha_encrypt_asymmetric(context.handle(), pk_.get(), plain.data(), plain.chain_index(), nonce, cipher.data(), s));
         cipher.set_ntt_form(true);
         cipher.set_scale(plain.scale());
     }
 };
 
 // ---- secret key (include/secretkey.h:150-290, src/secretkey.cu) -----------------------------------
-// Randomness: the reference seeds every draw from std::random_device; here one 64-bit seed given
-// at construction (default: std::random_device) determines every later draw, so runs can be
-// reproduced.  Distributions are the reference's (src/prng.cu).
+// Randomness: a ChaCha20 stream under the process's 256-bit sampler key (OS entropy; include/phantom_amd.h).  The 64-bit
+// value given at construction (default: std::random_device) only numbers this key's draws — a public nonce base, not a
+// secret; with the sampler key fixed by pha_set_sampler_key (tests) runs are reproducible.  Distributions are the
+// reference's (src/prng.cu).
 class PhantomSecretKey {
     device_words sk_;  // secret_key_array(): [size_QP][N], NTT form
     bool gen_flag_ = false;
     uint64_t seed_, draws_ = 0;
 
-    uint64_t next_seed() {  // SplitMix64 over the construction seed
+    uint64_t next_seed() {  // distinct nonces: a bijective mix of (construction value, draw number)
         uint64_t z = seed_ + (++draws_) * 0x9E3779B97F4A7C15ULL;
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
@@ -501,7 +500,6 @@ public:
         PhantomPublicKey pk;
         pk.pk_ = device_words(2 * context.key_parms().coeff_modulus().size() * context.poly_degree());
         check(pha_gen_publickey(context.handle(), sk_.get(), next_seed(), pk.pk_.get(), sw.get_stream()));
-        pk.seed_ = next_seed();
         return pk;
     }
     PhantomGaloisKey create_galois_keys_from_elts(const PhantomContext &context, const std::vector<uint32_t> &elts,

@@ -31,6 +31,10 @@ def gpu(pha):
     import torch
     assert os.path.exists(pha.LIB_PATH), "libphantom_amd.so missing on the GPU box: build it in-tree first"
     pha.lib()
+    # key material is compared with the oracle bit for bit: both sides sample under the oracle's fixed key (the
+    # library's own default is 32 bytes of OS entropy; tests/test_keygen.py checks that default too)
+    import oracle
+    pha.set_sampler_key(oracle.SAMPLER_KEY)
     assert torch.cuda.is_available(), "GPU test selected but no HIP device is visible"
     torch.cuda.set_device(0)
     return torch

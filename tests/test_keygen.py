@@ -52,6 +52,51 @@ def test_sampler_distributions(orc):
     assert (o.sample("uniform", 2, 7) != o.sample("uniform", 2, 8)).mean() > 0.99
 
 
+def test_chacha20_block_known_answer(orc):
+    """RFC 8439 section 2.3.2: key 00..1f, block counter 1, nonce 00 00 00 09 00 00 00 4a 00 00 00 00.  The sampler's
+    counter / nonce words are (ctr_lo, ctr_hi, seed_lo, seed_hi), so that vector is ctr = 1 | 0x09000000 << 32,
+    seed = 0x4a000000."""
+    key = [int.from_bytes(bytes(range(4 * i, 4 * i + 4)), "little") for i in range(8)]
+    out = orc.chacha20_block(key, 0x4A000000, 1 | (0x09000000 << 32))
+    assert out == [0xE4E7F110, 0x15593BD1, 0x1FDD0F50, 0xC47120A3, 0xC7F4D1C7, 0x0368C033, 0x9AAA2204, 0x4E6CD4C3,
+                   0x466482D2, 0x09AA9F07, 0x05D7C214, 0xA2028BD9, 0xD19C12B5, 0xB94E16DE, 0xE883D0CB, 0x4E3C50A2]
+    # rnd(seed, ctr) = the first 64 bits of the block under the oracle's (all-zero) key
+    w = orc.chacha20_block([0] * 8, 7, 9)
+    assert orc.rnd_at(7, 9) == w[0] | (w[1] << 32)
+
+
+def test_library_nonces_and_sampler_key_entry_points(pha):
+    """no GPU needed: the entry points exist and OS-entropy nonces do not repeat"""
+    pha.lib()
+    assert len({pha.random_nonce() for _ in range(64)}) == 64
+    pha.set_sampler_key(bytes(range(32)))
+    pha.set_sampler_key(None)
+
+
+@pytest.mark.gpu
+def test_default_sampler_key_is_os_entropy(gpu, pha, orc):
+    """The library's default state: a 256-bit key from OS entropy.  The same nonce then gives unrelated streams from
+    one key to the next (nothing about a draw can be recomputed from its nonce or from another draw), while under
+    the fixed test key the nonce determines the draw."""
+    mods, o = _setup(orc, CHAINS[0])
+    ctx = pha.PhantomContext(LOG_N, mods, 2)
+    try:
+        pha.set_sampler_key(None)
+        a = pha.to_host(ctx.gen_secretkey(5))
+        ct_a = pha.to_host(ctx.encrypt_zero_symmetric(ctx.gen_secretkey(5), 1, 77, 78))
+        pha.set_sampler_key(None)
+        b = pha.to_host(ctx.gen_secretkey(5))
+        ct_b = pha.to_host(ctx.encrypt_zero_symmetric(ctx.gen_secretkey(5), 1, 77, 78))
+        assert (a != b).mean() > 0.3                      # two ternary keys, NTT form: unrelated
+        assert (ct_a[1] != ct_b[1]).mean() > 0.99         # the published uniform part under the same nonce: unrelated
+        pha.set_sampler_key(orc.SAMPLER_KEY)
+        c1, c2 = pha.to_host(ctx.gen_secretkey(5)), pha.to_host(ctx.gen_secretkey(5))
+        assert (c1 == c2).all() and (c1 == o.gen_secretkey(5)).all()
+    finally:
+        pha.set_sampler_key(orc.SAMPLER_KEY)
+        ctx.close()
+
+
 @pytest.mark.parametrize("chain_id", [0, 1])
 def test_oracle_keys_decrypt(orc, chain_id):
     from oracle.ckks_ref import negacyclic_mul
