@@ -11,22 +11,37 @@ DEPS = SOURCES + ["modarith.cuh", "ntt_kernels.cuh", "rns_kernels.cuh", "keygen_
                   os.path.join("..", "..", "include", "phantom_amd.h")]
 
 
-def _stale():
+CMD_FILE = OUT + ".cmd"        # the command line the library was built with: other flags (PHA_EXTRA_DEFINES) = stale
+
+
+def _command():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    return [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", *os.environ.get("PHA_EXTRA_DEFINES", "").split(),
+            *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
+
+
+def _stale(cmd):
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    if any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS):
+        return True
+    # a library without its .cmd file was built elsewhere (it travels to the GPU box without one only if deleted): a GPU
+    # box has no reason to rebuild, so only a recorded, different command counts
+    return os.path.exists(CMD_FILE) and open(CMD_FILE).read().strip() != " ".join(cmd)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+def build(force=False, verbose=True):
+    """Compile the library if a source is newer than it, the flags changed, or `force`; prints the hipcc command when it
+    compiles (verbose) so that a log shows what the library under test was built from."""
+    cmd = _command()
+    if not force and not _stale(cmd):
         return OUT
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", *os.environ.get("PHA_EXTRA_DEFINES", "").split(),
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
     if verbose:
-        print(" ".join(cmd))
+        print("[build] " + " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
+    with open(CMD_FILE, "w") as f:
+        f.write(" ".join(cmd) + "\n")
     return OUT
 
 

@@ -615,10 +615,14 @@ class ResNetCifar10:
         import torch
         from .ckks import Ct
         static_in = TensorCipher(x.logn, x.k, x.h, x.w, x.c, x.t, x.p, Ct(x.ct.data.clone(), x.ct.level, x.ct.scale))
-        # pairs of streams only: ending the capture of a four-stream tree (nested run_pair) crashes inside hipGraph
-        # (ROCm 7.2); the graph is no faster than eager issue anyway
+        # A forked stream that forks again (run_pair inside run_pair) sends hipStreamEndCapture of the HIP runtime bundled
+        # with torch (7.0) into an endless recursion over the streams' parallel-capture lists; ROCm 7.2's runtime ends the
+        # same capture correctly (HIP-only reproducer and backtrace: profiles/r2c_hipgraph_nested_fork.md).  Under the old
+        # runtime the capture uses pairs of streams only; PHA_CAPTURE_NEST overrides the depth.
         cls = type(self.ev)
-        nest, cls.MAX_NEST = cls.MAX_NEST, 1
+        hip = tuple(int(v) for v in (torch.version.hip or "0.0").split(".")[:2])
+        depth = int(os.environ.get("PHA_CAPTURE_NEST", cls.MAX_NEST if hip >= (7, 2) else 1))
+        nest, cls.MAX_NEST = cls.MAX_NEST, min(cls.MAX_NEST, depth)
         try:
             return self._capture(static_in)
         finally:

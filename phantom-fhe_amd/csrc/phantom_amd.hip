@@ -50,10 +50,17 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// tables of a level / Galois element / merged rescale are built and uploaded on first use: under a stream capture in
+// global mode (torch.cuda.graph's default) those copies are refused and the capture is invalidated
+inline const char *capture_hint(hipError_t e) {
+    return (e == hipErrorStreamCaptureUnsupported || e == hipErrorStreamCaptureInvalidated || e == hipErrorStreamCaptureImplicit)
+               ? " (a table is built on first use: run the call once, or pha_prepare_level, before capturing)" : "";
+}
+
 #define HIP_TRY(expr)                                                                                    \
     do {                                                                                                 \
         hipError_t e_ = (expr);                                                                          \
-        if (e_ != hipSuccess) return fail(PHA_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+        if (e_ != hipSuccess) return fail(PHA_ERR_HIP, "%s failed: %s%s", #expr, hipGetErrorString(e_), capture_hint(e_)); \
     } while (0)
 
 #define PHA_TRY(expr)             \
@@ -152,6 +159,9 @@ struct pha_context {
     std::map<size_t, std::unique_ptr<LevelTool>> levels;
     std::map<uint32_t, std::unique_ptr<DevBuf<uint32_t>>> galois_tables;
     DevBuf<uint64_t> workspace;
+    hipStream_t ws_stream = nullptr;   // the stream of the last call that took the workspace (ensure_workspace)
+    bool ws_used = false;
+    hipEvent_t ws_event = nullptr;
     DevBuf<uint64_t> d_bigP_mod_q;  // key level, [size_Q] (key generation)
     // helper stream for the independent giant-step chains of pha_linear_transform_double_hoisted
     static constexpr int kAuxStreams = 3;                // helper streams of the double-hoisted transform's giant chains
@@ -182,12 +192,35 @@ struct pha_context {
 
 namespace {
 
-int ensure_workspace(pha_context *ctx, size_t words, uint64_t **out) {
+// The context's one workspace, for a call on stream `st`.  Calls on one stream are ordered by the stream; when a call
+// arrives on another stream than the last one, the new stream first waits for everything enqueued on the old one (an
+// event recorded there now), so two streams sharing a context are serialised instead of racing on t_mod_up / cx /
+// scratch.  Concurrent work needs one context per stream (ckks.py: GpuEvaluator.sibling).  Growing the buffer
+// synchronises the device and allocates: not possible while `st` is capturing -- run the call once before the capture.
+int ensure_workspace(pha_context *ctx, size_t words, uint64_t **out, hipStream_t st) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    HIP_TRY(hipStreamIsCapturing(st, &cap));
     if (ctx->workspace.count < words) {
+        if (cap != hipStreamCaptureStatusNone)
+            return fail(PHA_ERR_LOGIC, "the workspace must grow to %zu words while the stream is capturing: run this call once before "
+                        "the capture", words);
         // the old buffer may still be in use by enqueued kernels
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(ctx->workspace.alloc(words));
+    } else if (ctx->ws_used && ctx->ws_stream != st) {
+        hipStreamCaptureStatus prev = hipStreamCaptureStatusNone;
+        const bool alive = hipStreamIsCapturing(ctx->ws_stream, &prev) == hipSuccess;   // the caller may have destroyed it
+        if (!alive) (void)hipGetLastError();
+        // a capturing stream may only wait for work of its own capture; what ran before the capture began was
+        // synchronised by whoever began it
+        if (alive && (cap == hipStreamCaptureStatusNone) == (prev == hipStreamCaptureStatusNone)) {
+            if (!ctx->ws_event) HIP_TRY(hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(ctx->ws_event, ctx->ws_stream));
+            HIP_TRY(hipStreamWaitEvent(st, ctx->ws_event, 0));
+        }
     }
+    ctx->ws_stream = st;
+    ctx->ws_used = true;
     *out = ctx->workspace.p;
     return PHA_OK;
 }
@@ -725,7 +758,7 @@ int do_keyswitch(pha_context *ctx, LevelTool *lt, uint64_t *ct, const uint64_t *
                  hipStream_t st, const uint64_t *addend = nullptr, uint32_t addend_every = 0) {
     const size_t n = ctx->n, size_Ql = lt->size_Ql, size_QlP = size_Ql + ctx->size_P;
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n, &ws));
+    PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n, &ws, st));
     uint64_t *t_mod_up = ws, *cx = t_mod_up + lt->beta * size_QlP * n, *scratch = cx + 2 * size_QlP * n;
     PHA_TRY(do_modup(ctx, lt, t_mod_up, c2, scratch, st));
     PHA_TRY(do_inner_prod(ctx, lt, cx, t_mod_up, evks, st));
@@ -893,7 +926,7 @@ int lp_moddown_finish(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *c
     if (!w.qc) return PHA_OK;
     const size_t n = ctx->n, size_Ql = lt->size_Ql, alpha = ctx->size_P, size_QlP = size_Ql + alpha;
     uint64_t *delta;
-    PHA_TRY(ensure_workspace(ctx, 2 * size_Ql * n, &delta));
+    PHA_TRY(ensure_workspace(ctx, 2 * size_Ql * n, &delta, st));
     if (alpha == 1) {
         hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(static_cast<uint32_t>(n / 512), 2u), dim3(256), 0, st, delta,
                            p_coeff + (p_rows ? p_rows[0] : 0) * n, ctx->d_mod.p, static_cast<uint32_t>(w.q0),
@@ -1253,6 +1286,7 @@ int pha_context_create(int log_n, const uint64_t *moduli_QP, size_t size_QP, siz
 void pha_context_destroy(pha_context *ctx) {
     if (!ctx) return;
     (void)hipDeviceSynchronize();
+    if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
     if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
     for (int c = 0; c < pha_context::kAuxStreams; c++) {
         if (ctx->aux_join[c]) (void)hipEventDestroy(ctx->aux_join[c]);
@@ -1409,7 +1443,7 @@ int pha_modup(pha_context *ctx, size_t chain_index, uint64_t *dst, const uint64_
     LevelTool *lt;
     PHA_TRY(get_level(ctx, chain_index, &lt));
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, lt->size_Ql * ctx->n, &ws));
+    PHA_TRY(ensure_workspace(ctx, lt->size_Ql * ctx->n, &ws, as_stream(stream)));
     return do_modup(ctx, lt, dst, cks, ws, as_stream(stream));
 }
 
@@ -1427,7 +1461,7 @@ int pha_moddown_from_ntt(pha_context *ctx, size_t chain_index, uint64_t *ct_i, u
     LevelTool *lt;
     PHA_TRY(get_level(ctx, chain_index, &lt));
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, lt->size_Ql * ctx->n, &ws));
+    PHA_TRY(ensure_workspace(ctx, lt->size_Ql * ctx->n, &ws, as_stream(stream)));
     return do_moddown(ctx, lt, ct_i, cx_i, ws, nullptr, 1, as_stream(stream));
 }
 
@@ -1470,7 +1504,7 @@ int pha_apply_galois_ntt(pha_context *ctx, const uint64_t *operand, size_t coeff
     hipStream_t st = as_stream(stream);
     if (result == operand) {
         uint64_t *ws;
-        PHA_TRY(ensure_workspace(ctx, coeff_mod_size * ctx->n, &ws));
+        PHA_TRY(ensure_workspace(ctx, coeff_mod_size * ctx->n, &ws, st));
         PHA_TRY(do_galois(ctx, operand, coeff_mod_size, perm, ws, st));
         HIP_TRY(hipMemcpyAsync(result, ws, coeff_mod_size * ctx->n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
         return PHA_OK;
@@ -1550,7 +1584,7 @@ int pha_apply_galois_inplace(pha_context *ctx, size_t chain_index, uint64_t *ct,
     // workspace: [key-switch scratch][temp for both permuted polys]
     const size_t ks_words = (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n;
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, ks_words + 2 * size_Ql * n, &ws));
+    PHA_TRY(ensure_workspace(ctx, ks_words + 2 * size_Ql * n, &ws, st));
     uint64_t *temp = ws + ks_words;
     // c0 <- galois(c0); temp1 <- galois(c1); c1 <- 0; ct += KS(temp1)   (src/evaluate.cu:774-793): the moddown
     // epilogue writes ct = (galois(c0), 0) + KS directly — no copy of galois(c0), no memset of c1
@@ -1565,7 +1599,7 @@ int pha_rescale_to_next(pha_context *ctx, size_t chain_index, const uint64_t *sr
     PHA_TRY(get_level(ctx, chain_index, &lt));
     if (lt->size_Ql < 2) return fail(PHA_ERR_INVALID_ARGUMENT, "end of modulus switching chain reached");
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, cipher_size * ctx->n, &ws));
+    PHA_TRY(ensure_workspace(ctx, cipher_size * ctx->n, &ws, as_stream(stream)));
     return rescale_with_scratch(ctx, lt, src, cipher_size, dst, ws, as_stream(stream));
 }
 
@@ -1745,7 +1779,7 @@ int pha_encrypt_zero_asymmetric(pha_context *ctx, const uint64_t *pk, size_t cha
     PHA_TRY(get_level(ctx, 1, &lt));
     // workspace: u[QP] | cx[2][QP] | delta[2][Q] | top[2][Q]
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, (3 * QP + 4 * Q) * n, &ws));
+    PHA_TRY(ensure_workspace(ctx, (3 * QP + 4 * Q) * n, &ws, st));
     uint64_t *u = ws, *cx = u + QP * n, *delta = cx + 2 * QP * n, *top = delta + 2 * Q * n;
     NttRange r;
     PHA_TRY(make_range(ctx, QP, 0, 0, 0, 0, 0, r));
@@ -1786,7 +1820,7 @@ int pha_ckks_decrypt(pha_context *ctx, const uint64_t *sk, const uint64_t *ct, s
     PHA_TRY(launch_ew(ctx, EW_MUL_ADD, plain, ct + limbs * n, sk, ct, nullptr, 0, limbs, st));
     if (cipher_size > 2) {
         uint64_t *sp;
-        PHA_TRY(ensure_workspace(ctx, limbs * n, &sp));
+        PHA_TRY(ensure_workspace(ctx, limbs * n, &sp, st));
         const uint64_t *prev = sk;
         for (size_t i = 2; i < cipher_size; i++) {
             PHA_TRY(launch_ew(ctx, EW_MUL, sp, prev, sk, nullptr, nullptr, 0, limbs, st));
@@ -1806,7 +1840,7 @@ int pha_generate_one_kswitch_key(pha_context *ctx, const uint64_t *sk, const uin
 int pha_gen_relinkey(pha_context *ctx, const uint64_t *sk, uint64_t seed, uint64_t *const *evks_host, pha_stream_t stream) {
     REQUIRE_CTX(sk && evks_host);
     uint64_t *s2;
-    PHA_TRY(ensure_workspace(ctx, ctx->size_Q * ctx->n, &s2));
+    PHA_TRY(ensure_workspace(ctx, ctx->size_Q * ctx->n, &s2, as_stream(stream)));
     PHA_TRY(launch_ew(ctx, EW_MUL, s2, sk, sk, nullptr, nullptr, 0, ctx->size_Q, as_stream(stream)));
     return do_kswitch_key(ctx, sk, s2, seed, evks_host, as_stream(stream));
 }
@@ -1817,7 +1851,7 @@ int pha_gen_galois_key(pha_context *ctx, const uint64_t *sk, uint32_t galois_elt
     const uint32_t *perm;
     PHA_TRY(get_galois_table(ctx, galois_elt, &perm));
     uint64_t *sg;
-    PHA_TRY(ensure_workspace(ctx, ctx->size_Q * ctx->n, &sg));
+    PHA_TRY(ensure_workspace(ctx, ctx->size_Q * ctx->n, &sg, as_stream(stream)));
     PHA_TRY(do_galois(ctx, sk, ctx->size_Q, perm, sg, as_stream(stream)));
     return do_kswitch_key(ctx, sk, sg, seed, evks_host, as_stream(stream));
 }
@@ -1900,7 +1934,7 @@ int do_ckks_encode(pha_context *ctx, const double *values_host, size_t values_si
     uint32_t log_s = 0;
     while ((1u << log_s) < S) log_s++;
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, 4 * s + 2, &ws));
+    PHA_TRY(ensure_workspace(ctx, 4 * s + 2, &ws, st));
     double2 *buf = reinterpret_cast<double2 *>(ws), *tmp = buf + s;
     unsigned long long *d_max = reinterpret_cast<unsigned long long *>(tmp + s);
     HIP_TRY(hipMemsetAsync(buf, 0, s * sizeof(double2), st));
@@ -1963,7 +1997,7 @@ int pha_ckks_decode(pha_context *ctx, const uint64_t *plain, size_t chain_index,
     uint32_t log_s = 0;
     while ((1u << log_s) < S) log_s++;
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, limbs * n + 4 * sparse_slots, &ws));
+    PHA_TRY(ensure_workspace(ctx, limbs * n + 4 * sparse_slots, &ws, st));
     uint64_t *copy = ws;
     double2 *buf = reinterpret_cast<double2 *>(ws + limbs * n), *tmp = buf + sparse_slots;
     NttRange r;
@@ -1991,7 +2025,7 @@ int pha_rotate_hoisted(pha_context *ctx, size_t chain_index, const uint64_t *ct,
     const size_t n = ctx->n, size_Ql = lt->size_Ql, size_QlP = size_Ql + ctx->size_P;
     hipStream_t st = as_stream(stream);
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n, &ws));
+    PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n, &ws, st));
     uint64_t *t_mod_up = ws, *cx = t_mod_up + lt->beta * size_QlP * n, *scratch = cx + 2 * size_QlP * n;
     PHA_TRY(do_modup(ctx, lt, t_mod_up, ct + size_Ql * n, scratch, st));  // once for every rotation
     for (size_t r = 0; r < n_rot; r++) {
@@ -2054,7 +2088,7 @@ int pha_linear_transform_double_hoisted(pha_context *ctx, size_t chain_index, co
         }
     const size_t chain_words = ((lt->beta + 6) * size_QlP + 4 * size_Ql) * n;   // t_mod_up | cx | acc | total | scratch | u
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, n_chains * chain_words + 2 * n_baby * size_QlP * n, &ws));
+    PHA_TRY(ensure_workspace(ctx, n_chains * chain_words + 2 * n_baby * size_QlP * n, &ws, st));
     struct Chain {
         hipStream_t st;
         uint64_t *t_mod_up, *cx, *acc, *total, *scratch, *u;
@@ -2102,6 +2136,10 @@ int pha_linear_transform_double_hoisted(pha_context *ctx, size_t chain_index, co
         HIP_TRY(hipEventRecord(ctx->aux_fork, st));
         for (size_t c = 1; c < n_chains; c++) HIP_TRY(hipStreamWaitEvent(ctx->aux_stream[c - 1], ctx->aux_fork, 0));
     }
+    // Once the helper streams have been forked they are joined below whatever happens in between: a helper left
+    // unjoined would keep running on this context's workspace after the call has returned its error, and under stream
+    // capture it would make the caller's hipStreamEndCapture fail (hipErrorStreamCaptureUnjoined).
+    auto giant_steps = [&]() -> int {
     size_t rot_index = 0;
     for (size_t g = 0; g < n_giant; g++) {
         MacTerms terms{};
@@ -2125,11 +2163,16 @@ int pha_linear_transform_double_hoisted(pha_context *ctx, size_t chain_index, co
         }
         PHA_TRY(accumulate(ch, add));
     }
+    return PHA_OK;
+    };
+    int rc = giant_steps();
     for (size_t c = 1; c < n_chains; c++) {  // join: the helper chains' partial sums go into the main one
-        HIP_TRY(hipEventRecord(ctx->aux_join[c - 1], ctx->aux_stream[c - 1]));
-        HIP_TRY(hipStreamWaitEvent(st, ctx->aux_join[c - 1], 0));
-        if (!chains[c].first) PHA_TRY(accumulate(main_chain, chains[c].total));
+        const hipError_t e1 = hipEventRecord(ctx->aux_join[c - 1], ctx->aux_stream[c - 1]);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(st, ctx->aux_join[c - 1], 0) : e1;
+        if (e2 != hipSuccess && rc == PHA_OK) rc = fail(PHA_ERR_HIP, "joining helper stream %zu: %s", c, hipGetErrorString(e2));
+        if (rc == PHA_OK && !chains[c].first) rc = accumulate(main_chain, chains[c].total);
     }
+    if (rc != PHA_OK) return rc;
     if (main_chain.first) return fail(PHA_ERR_INVALID_ARGUMENT, "the transform has no plaintext");
     return do_moddown(ctx, lt, out, main_chain.total, main_chain.scratch, nullptr, 2, st);
 }
@@ -2152,7 +2195,7 @@ int pha_apply_galois_batched(pha_context *ctx, size_t chain_index, const uint64_
         for (size_t b = 0; b < batch; b++) {
             PHA_TRY(do_galois(ctx, in + b * ct_words, 2 * size_Ql, perm, out + b * ct_words, st));
             uint64_t *ws;
-            PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 3 * size_Ql) * n, &ws));
+            PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 3 * size_Ql) * n, &ws, st));
             uint64_t *c2 = ws + (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n;
             HIP_TRY(hipMemcpyAsync(c2, out + b * ct_words + size_Ql * n, size_Ql * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
             HIP_TRY(hipMemsetAsync(out + b * ct_words + size_Ql * n, 0, size_Ql * n * sizeof(uint64_t), st));
@@ -2162,7 +2205,7 @@ int pha_apply_galois_batched(pha_context *ctx, size_t chain_index, const uint64_
     }
     // workspace: t_mod_up [batch][beta][QlP] | cx [batch][2][QlP] | t_cks [batch][2][Ql] (poly 1 slots used) | delta [2 batch][Ql]
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, batch * (lt->beta * size_QlP + 2 * size_QlP + 4 * size_Ql) * n, &ws));
+    PHA_TRY(ensure_workspace(ctx, batch * (lt->beta * size_QlP + 2 * size_QlP + 4 * size_Ql) * n, &ws, st));
     uint64_t *t_mod_up = ws, *cx = t_mod_up + batch * lt->beta * size_QlP * n, *t_cks = cx + batch * 2 * size_QlP * n,
              *delta = t_cks + batch * ct_words;
     // permute both polys of every ciphertext (src/evaluate.cu:747-794)
@@ -2193,7 +2236,7 @@ int pha_multiply_relin_rescale(pha_context *ctx, size_t chain_index, const uint6
         HIP_TRY(ctx->d_bigP_mod_q.upload(lc.bigP_mod_q));
     }
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 5 * size_Ql) * n, &ws));
+    PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 5 * size_Ql) * n, &ws, st));
     uint64_t *t_mod_up = ws, *cx = t_mod_up + lt->beta * size_QlP * n, *scratch = cx + 2 * size_QlP * n, *d = scratch + 2 * size_Ql * n;
     {   // tensor product, doubled here when asked: before the division the doubling is exact
         const dim3 tg(static_cast<uint32_t>(size_Ql) * (static_cast<uint32_t>(n) / 512));
@@ -2243,7 +2286,7 @@ int pha_multiply_relin_rescale_batched(pha_context *ctx, size_t chain_index, siz
     // delta [2 batch][Ql]
     const size_t d_words = 3 * size_Ql * n;
     uint64_t *ws;
-    PHA_TRY(ensure_workspace(ctx, batch * (lt->beta * size_QlP + 2 * size_QlP + 2 * 3 * size_Ql + 2 * size_Ql) * n, &ws));
+    PHA_TRY(ensure_workspace(ctx, batch * (lt->beta * size_QlP + 2 * size_QlP + 2 * 3 * size_Ql + 2 * size_Ql) * n, &ws, st));
     uint64_t *t_mod_up = ws, *cx = t_mod_up + batch * lt->beta * size_QlP * n, *d = cx + batch * 2 * size_QlP * n,
              *t_cks = d + batch * d_words, *delta = t_cks + batch * d_words;
     const uint32_t n32 = static_cast<uint32_t>(n), ql = static_cast<uint32_t>(size_Ql), qlp = static_cast<uint32_t>(size_QlP);
@@ -2272,7 +2315,7 @@ int pha_mod_raise(pha_context *ctx, const uint64_t *src, uint64_t *dst, pha_stre
     hipStream_t st = as_stream(stream);
     const size_t n = ctx->n, limbs = ctx->size_Q;
     uint64_t *coeff;
-    PHA_TRY(ensure_workspace(ctx, 2 * n, &coeff));
+    PHA_TRY(ensure_workspace(ctx, 2 * n, &coeff, st));
     // limb 0 of both polys to coefficient form (the lowest level has one limb: polys are n apart)
     NttRange r0;
     PHA_TRY(make_range(ctx, 1, 0, 0, 0, 0, 0, r0));

@@ -18,7 +18,7 @@ def _chain(orc, extra=()):
 
 def test_chebyshev_and_linear_transform_on_the_simulator(orc, pha):
     from phantom_fhe_amd.bootstrap import ChebyshevEvaluator, LinearTransform
-    from phantom_fhe_amd.ckks import SimEvaluator
+    from oracle.sim_evaluator import SimEvaluator
     ev = SimEvaluator(LOG_N, _chain(orc), 16, seed=1)
     rng = np.random.default_rng(0)
     w = rng.uniform(-1, 1, 16)
@@ -38,7 +38,7 @@ def test_chebyshev_and_linear_transform_on_the_simulator(orc, pha):
 @pytest.mark.parametrize("s,packed", [(4, True), (16, True), (64, True), (16, False)])
 def test_bootstrap_on_the_simulator(orc, pha, s, packed):
     from phantom_fhe_amd.bootstrap import Bootstrapper
-    from phantom_fhe_amd.ckks import SimEvaluator
+    from oracle.sim_evaluator import SimEvaluator
     q = _chain(orc)
     ev = SimEvaluator(LOG_N, q, s, hamming_weight=32, seed=s)
     bs = Bootstrapper(ev, K=12, r=3, degree=31, packed=packed)
@@ -86,7 +86,7 @@ def test_special_fft_factorisation():
 def test_fft_bootstrap_on_the_simulator(orc, pha, log_n, s, groups):
     """FFT-factored CoeffToSlot / SlotToCoeff, sparse and FULL slots (s = N/2: no SubSum)"""
     from phantom_fhe_amd.bootstrap import Bootstrapper
-    from phantom_fhe_amd.ckks import SimEvaluator
+    from oracle.sim_evaluator import SimEvaluator
     n = 1 << log_n
     q = [int(v) for v in _fft_chain(orc, n, groups)]
     ev = SimEvaluator(log_n, q, s, hamming_weight=32, seed=s)
@@ -105,7 +105,7 @@ def test_slim_bootstrap_on_the_simulator(orc, pha, log_n, s, groups):
     """SlotToCoeff first (on the last levels), then modulus raise, CoeffToSlot, EvalMod: the output scale is the
     input scale by the choice of the EvalMod scale, whatever the input scale is"""
     from phantom_fhe_amd.bootstrap import Bootstrapper
-    from phantom_fhe_amd.ckks import SimEvaluator
+    from oracle.sim_evaluator import SimEvaluator
     n = 1 << log_n
     q = [int(v) for v in _fft_chain(orc, n, groups)]
     ev = SimEvaluator(log_n, q, s, hamming_weight=32, seed=s)

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import phantom_fhe_amd as pha                                    # noqa: E402
 from phantom_fhe_amd import cnn                                  # noqa: E402
-from phantom_fhe_amd.ckks import SimEvaluator                    # noqa: E402
+from oracle.sim_evaluator import SimEvaluator                    # noqa: E402
 from oracle import cnn_ref                                       # noqa: E402
 
 LOGN = 10                                                        # slots of the simulator's ring (N = 2^11)

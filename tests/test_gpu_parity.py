@@ -191,6 +191,68 @@ def test_keyswitch_pipeline(gpu, pha, orc, size_p, chain_index):
     ctx.close()
 
 
+def test_one_context_on_two_streams_is_serialised(gpu, pha, orc):
+    """Two streams taking turns on ONE context share its workspace: the library makes the second stream wait for what the
+    first enqueued (ensure_workspace) instead of letting the key switches race on t_mod_up / cx.  N = 2^15 so that each
+    call runs long enough to overlap if nothing ordered them."""
+    log_n, n, size_p = 15, 1 << 15, 2
+    mods = orc.coeff_modulus_create(n, [45] * 6 + [55] * size_p)
+    ctx, o = pha.PhantomContext(log_n, mods, size_p), orc.Oracle(log_n, mods, size_p)
+    evk_h, evk_d = _uniform_evk(pha, o, 70)
+    lim = list(range(6))
+    cts = [np.stack([o.uniform_poly(lim, 20 + 3 * i), o.uniform_poly(lim, 21 + 3 * i)]) for i in range(2)]
+    c2s = [o.uniform_poly(lim, 22 + 3 * i) for i in range(2)]
+    refs = []
+    for ct, c2 in zip(cts, c2s):
+        r = ct.copy()
+        o.keyswitch_inplace(6, r, c2, evk_h)
+        refs.append(r)
+    streams = [gpu.cuda.Stream(), gpu.cuda.Stream()]
+    d_cts = [[_dev(pha, ct) for _ in range(4)] for ct in cts]
+    d_c2s = [_dev(pha, c2) for c2 in c2s]
+    ctx.keyswitch_inplace(1, _dev(pha, cts[0]), d_c2s[0], evk_d)          # tables and workspace
+    gpu.cuda.synchronize()
+    for rep in range(4):
+        for i in range(2):
+            with gpu.cuda.stream(streams[i]):
+                ctx.keyswitch_inplace(1, d_cts[i][rep], d_c2s[i], evk_d)
+    gpu.cuda.synchronize()
+    for i in range(2):
+        for rep in range(4):
+            assert (_host(pha, d_cts[i][rep]) == refs[i]).all(), (i, rep)
+    ctx.close()
+
+
+def test_workspace_growth_under_capture_is_refused(gpu, pha, orc):
+    """A call that would have to grow the workspace (device synchronisation + allocation) while its stream is capturing
+    returns PHA_ERR_LOGIC before touching the capture; after one eager call the same call captures and replays exactly."""
+    mods = orc.coeff_modulus_create(4096, [45] * 6 + [55] * 2)
+    ctx, o = pha.PhantomContext(12, mods, 2), orc.Oracle(12, mods, 2)
+    evk_h, evk_d = _uniform_evk(pha, o, 70)
+    lim = list(range(6))
+    ct = np.stack([o.uniform_poly(lim, 7), o.uniform_poly(lim, 8)])
+    c2 = o.uniform_poly(lim, 6)
+    ref = ct.copy()
+    o.keyswitch_inplace(6, ref, c2, evk_h)
+    ctx.prepare_level(1)                                                    # tables yes, workspace no
+    d_ct, d_c2 = _dev(pha, ct), _dev(pha, c2)
+    gpu.cuda.synchronize()
+    graph = gpu.cuda.CUDAGraph()
+    with gpu.cuda.graph(graph):
+        with pytest.raises(pha.PhantomError) as err:
+            ctx.keyswitch_inplace(1, d_ct, d_c2, evk_d)
+    assert err.value.code == pha.PHA_ERR_LOGIC and "capturing" in str(err.value)
+    ctx.keyswitch_inplace(1, _dev(pha, ct), d_c2, evk_d)
+    gpu.cuda.synchronize()
+    graph = gpu.cuda.CUDAGraph()
+    with gpu.cuda.graph(graph):
+        ctx.keyswitch_inplace(1, d_ct, d_c2, evk_d)
+    graph.replay()
+    gpu.cuda.synchronize()
+    assert (_host(pha, d_ct) == ref).all()
+    ctx.close()
+
+
 def test_galois_and_rotate(gpu, pha, orc, small):
     ctx, o = small
     size_ql = 6
@@ -310,6 +372,23 @@ def test_double_hoisted_linear_transform(gpu, pha, orc, size_p, chain_index):
     assert (_host(pha, out) == ref).all()
     with pytest.raises(pha.PhantomError):
         ctx.linear_transform_double_hoisted(chain_index, _dev(pha, ct), [1], [None], [1], [None], [[None]])
+    # an error after the helper streams were forked (the last rotating giant step has no key) still joins them: captured
+    # as a HIP graph, the failing call leaves nothing unjoined (the capture ends cleanly) and the next call is exact
+    bad_keys = [keys[e][1] if e != 1 else None for e in giant_elts[:-1]] + [None]
+    args = (chain_index, _dev(pha, ct), baby_elts, [keys[e][1] if e != 1 else None for e in baby_elts], giant_elts)
+    ctx.linear_transform_double_hoisted(*args, [keys[e][1] if e != 1 else None for e in giant_elts], d_pl)   # tables, workspace
+    gpu.cuda.synchronize()
+    graph = gpu.cuda.CUDAGraph()
+    with gpu.cuda.graph(graph):
+        with pytest.raises(pha.PhantomError) as err:
+            ctx.linear_transform_double_hoisted(*args, bad_keys, d_pl)
+        out = ctx.linear_transform_double_hoisted(*args, [keys[e][1] if e != 1 else None for e in giant_elts], d_pl)
+    assert err.value.code == pha.PHA_ERR_INVALID_ARGUMENT
+    graph.replay()
+    gpu.cuda.synchronize()
+    ref = linear_transform_double_hoisted_ref(o, size_ql, ct, baby_elts, [keys[e][0] if e != 1 else None for e in baby_elts],
+                                              giant_elts, [keys[e][0] if e != 1 else None for e in giant_elts], plains)
+    assert (_host(pha, out) == ref).all()
     ctx.close()
 
 

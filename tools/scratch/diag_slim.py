@@ -4,7 +4,8 @@ import numpy as np, torch
 import oracle as orc
 import phantom_fhe_amd as pha
 from phantom_fhe_amd.bootstrap import Bootstrapper
-from phantom_fhe_amd.ckks import GpuEvaluator, SimEvaluator
+from phantom_fhe_amd.ckks import GpuEvaluator
+from oracle.sim_evaluator import SimEvaluator
 LOG_N, N = 12, 4096
 for s, groups, d, e in ((2048, 3, 50, 50), (128, 2, 40, 40)):
     mods = orc.coeff_modulus_create(N, [d + 10] + [d] * 2 + [d] * groups + [e] * 9 + [min(60, d + 18)] * groups + [60])

@@ -1,0 +1,15 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+import phantom_fhe_amd as pha
+N, size_q, size_p = 65536, 36, 12
+mods = pha.coeff_modulus_create(N, [60] + [50] * (size_q - 1) + [60] * size_p)
+ctx = pha.PhantomContext(16, mods, size_p)
+g = torch.Generator(device="cuda").manual_seed(1)
+lo = int(mods.min())
+rnd = lambda *s: torch.randint(0, lo, (*s, N), dtype=torch.int64, device="cuda", generator=g)
+evk = pha.EvalKey([rnd(2, size_q + size_p) for _ in range(3)])
+ct1, ct2 = rnd(3, size_q), rnd(2, size_q)
+for _ in range(int(os.environ.get("REPS", "60"))):
+    ctx.multiply_and_relin_inplace(1, ct1, ct2, evk)
+torch.cuda.synchronize()
