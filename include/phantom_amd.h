@@ -121,6 +121,7 @@ int pha_ntt_launch_phase(pha_context *ctx, uint64_t *inout, size_t polys, size_t
                          size_t coeff_modulus_size, size_t start_modulus_idx, int inverse, int phase,
                          pha_stream_t stream);
 
+
 /* Block placement of the NTT kernels (no reference counterpart; the reference's grid-stride kernels have no placement,
  * src/ntt/fntt_2d.cu:625-652): limb_to_xcd != 0 (default) runs every tile of a limb, in both kernels of a transform, on
  * one XCD; 0 restores the tile-interleaved placement.  A speed setting for A/B measurements; results are identical. */

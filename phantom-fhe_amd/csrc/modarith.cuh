@@ -214,10 +214,21 @@ struct IntField {
 //   |t| <= (1/2 + 1.5 |y| / 2^52) q   (< 2q for |y| <= 4q <= 2^52).
 struct FpField {
     using elem = double;
-    using twt = double2;  // {w, ~w/q}
+#ifndef PHA_FP_QUOTIENT_FROM_W
+#define PHA_FP_QUOTIENT_FROM_W 0
+#endif
+#if PHA_FP_QUOTIENT_FROM_W
+    using twt = double2;  // {w, ~w/q}: the quotient estimate is y * (w/q), one more product per twiddle fetched (round 1)
+#else
+    using twt = double;   // the quotient estimate comes from the product's high part: rint(fl(y*w) * (1/q))
+#endif
     using twl = double;   // stored form
     double q, qinv;
+#if PHA_FP_QUOTIENT_FROM_W
     __device__ __forceinline__ twt prep(twl w) const { return twt{w, w * qinv}; }
+#else
+    __device__ __forceinline__ twt prep(twl w) const { return w; }
+#endif
     __device__ __forceinline__ explicit FpField(const DModulus &mod)
         : q(static_cast<double>(static_cast<int64_t>(mod.value))), qinv(1.0 / q) {}
     // 0 <= v < 2^52: splice into the mantissa of 2^52 and subtract
@@ -230,15 +241,21 @@ struct FpField {
     }
     __device__ __forceinline__ static uint64_t raw(elem v) { return static_cast<uint64_t>(__double_as_longlong(v)); }
     __device__ __forceinline__ static elem unraw(uint64_t r) { return __longlong_as_double(static_cast<long long>(r)); }
-    __device__ __forceinline__ twt make_cst(uint64_t c, uint64_t) const {
-        const double w = from_u64(c);
-        return twt{w, w * qinv};
-    }
+    __device__ __forceinline__ twt make_cst(uint64_t c, uint64_t) const { return prep(from_u64(c)); }
+    // y * w mod q as a representative of absolute value <= (1/2 + 3 * 2^-53 * |y| * w / q) q: h + l = y * w exactly
+    // (h the rounded product, l its error), c the rounded quotient estimate (three roundings off y*w/q either way:
+    // fl(y*w), 1/q and the product; or w/q, its product with y and 1/q), h - c*q exact in the FMA
     __device__ __forceinline__ elem mulmod(elem y, const twt &w) const {
 #pragma clang fp contract(off)
+#if PHA_FP_QUOTIENT_FROM_W
         const double h = y * w.x;
         const double l = __builtin_fma(y, w.x, -h);
         const double c = __builtin_rint(y * w.y);
+#else
+        const double h = y * w;
+        const double l = __builtin_fma(y, w, -h);
+        const double c = __builtin_rint(h * qinv);
+#endif
         return __builtin_fma(-c, q, h) + l;
     }
     __device__ __forceinline__ elem reduce(elem x) const {

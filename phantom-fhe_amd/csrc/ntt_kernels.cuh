@@ -100,9 +100,16 @@ enum : int { EPI_NONE = 0, EPI_SUB_MUL = 1, EPI_SUB_MUL_ADD = 2, EPI_SCALE = 3 }
 #define PHA_NT_STORES 0
 #endif
 #ifndef PHA_SC1_STORES
-#define PHA_SC1_STORES 0
+#define PHA_SC1_STORES 2
 #endif
 typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+// threadIdx.x as a value the optimiser cannot see through: inside a persistent loop (ntt_fused.cuh) everything derived
+// from the lane index would otherwise be hoisted out of the loop (300 VGPRs of addresses and LDS offsets, spilled)
+__device__ __forceinline__ uint32_t pha_tid() {
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
 __device__ __forceinline__ void st_stream(uint64_t *p, uint64_t v) {
 #if PHA_SC1_STORES >= 2
     asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
@@ -111,6 +118,9 @@ __device__ __forceinline__ void st_stream(uint64_t *p, uint64_t v) {
 #else
     *p = v;
 #endif
+}
+__device__ __forceinline__ void st_sc1(uint64_t *p, uint64_t v) {
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void st_stream2(uint64_t *p, ulonglong2 v) {
 #if PHA_SC1_STORES
@@ -340,18 +350,19 @@ __device__ __forceinline__ void fntt_col_load(uint64_t (&raw)[16], const uint64_
     constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA;
 #pragma unroll
     for (int g = 0; g < GA; g++) {
-        const uint32_t gid = threadIdx.x + kThreads * g, c = gid % C, r_lo = gid / C;
+        const uint32_t gid = pha_tid() + kThreads * g, c = gid % C, r_lo = gid / C;
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) raw[(g << RA) + j] = base[static_cast<size_t>((j << RB) | r_lo) * n2 + c];
     }
 }
-template <int S1, int RA, class F>
+// SC1: the result is stored write-through (hand-off to the row pass inside one launch, ntt_fused.cuh)
+template <int S1, int RA, bool SC1 = false, class F>
 __device__ __forceinline__ void fntt_col_body(uint64_t *lds, const uint64_t (&raw)[16], uint64_t *base, const tw_t *tw_raw,
                                               uint32_t n2, uint32_t root, const F &f) {
     constexpr int RB = S1 - RA, C = kTile >> S1, GA = 16 >> RA, GB = 16 >> RB;
     using TW = typename F::twl;
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
-    const uint32_t t = threadIdx.x;
+    const uint32_t t = pha_tid();
     PHA_TRACE_MARK(0);
 #pragma unroll
     for (int g = 0; g < GA; g++) {
@@ -374,7 +385,13 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, const uint64_t (&ra
         for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(lds[lds_col<C, RB>((r_hi << RB) | j, c)]);
         ct_radix<RB, RA>(x, CanonTw<TW>{tw, (root << RA) + r_hi}, f);
 #pragma unroll
-        for (int j = 0; j < (1 << RB); j++) st_stream(&base[static_cast<size_t>((r_hi << RB) | j) * n2 + c], F::raw(x[j]));
+        for (int j = 0; j < (1 << RB); j++) {
+            uint64_t *p = &base[static_cast<size_t>((r_hi << RB) | j) * n2 + c];
+            if (SC1)
+                st_sc1(p, F::raw(x[j]));
+            else
+                st_stream(p, F::raw(x[j]));
+        }
     }
     PHA_TRACE_MARK(3);
 #ifdef PHA_TRACE
@@ -413,7 +430,7 @@ __device__ __forceinline__ void fntt_row_load(uint64_t (&raw)[16], const uint64_
     constexpr int RB = S2 - RA, L = 1 << S2, GC = 16 >> RA;
 #pragma unroll
     for (int g = 0; g < GC; g++) {
-        const uint32_t gid = threadIdx.x + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;
+        const uint32_t gid = pha_tid() + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) raw[(g << RA) + j] = base[a * L + ((j << RB) | b_lo)];
     }
@@ -426,7 +443,7 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, const uint64_t (&ra
     constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
     using TW = typename F::twl;
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
-    const uint32_t t = threadIdx.x;
+    const uint32_t t = pha_tid();
 #pragma unroll
     for (int g = 0; g < GC; g++) {
         const uint32_t gid = t + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;

@@ -19,6 +19,9 @@
 
 #include "../../include/phantom_amd.h"
 #include "ntt_kernels.cuh"
+#ifdef PHA_EXPERIMENT_SINGLE_LAUNCH  // measured and rejected (profiles/r2c_single_launch.md); kept buildable for re-measurement
+#include "../../tools/scratch/ntt_single_launch_experiment.cuh"
+#endif
 #include "numth.hpp"
 #include "rns_kernels.cuh"
 #include "keygen_kernels.cuh"
@@ -178,6 +181,10 @@ struct pha_context {
     int num_cus = 0;
     int device = -1;          // the device this context was created on
     uint32_t xcd_map = 1;     // limb-to-XCD block placement of the NTT kernels (PHA_XCD_MAP=0: tile-interleaved, round 1)
+#ifdef PHA_EXPERIMENT_SINGLE_LAUNCH
+    int fused = 0, fused_wgs = 4, fused_depth = 4;
+    DevBuf<uint32_t> fused_ctl;
+#endif
 
     NttTables fwd_tables() const {
         return NttTables{d_mod.p, d_tw.p, d_twD.p, d_n_inv.p, d_n_inv_shoup.p, static_cast<uint32_t>(log_n), twD_stride,
@@ -397,11 +404,41 @@ void set_placement(LimbMap &lm, bool xcd, size_t polys) {
     lm.xcd_map = xcd ? 1u : 0u;
     lm.polys_magic = static_cast<uint32_t>(((1ull << 32) + polys - 1) / polys);
 }
+#ifdef PHA_EXPERIMENT_SINGLE_LAUNCH
+template <int S1, int RA1, int S2, int RA2>
+void launch_fused(bool narrow, int epi, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, const NttTables &T, const LimbMap &lm,
+                  const Epilogue &ep, const FusedArgs &fa) {
+#define PHA_FUSED_LAUNCH(E, NARROW) \
+    hipLaunchKernelGGL((fntt_fused_kernel<S1, RA1, S2, RA2, E, NARROW>), grid, dim3(kThreads), 0, st, data, ps, T, lm, ep, fa)
+    if (narrow) {
+        if (epi == EPI_SUB_MUL) PHA_FUSED_LAUNCH(EPI_SUB_MUL, true);
+        else if (epi == EPI_SUB_MUL_ADD) PHA_FUSED_LAUNCH(EPI_SUB_MUL_ADD, true);
+        else PHA_FUSED_LAUNCH(EPI_NONE, true);
+    } else {
+        if (epi == EPI_SUB_MUL) PHA_FUSED_LAUNCH(EPI_SUB_MUL, false);
+        else if (epi == EPI_SUB_MUL_ADD) PHA_FUSED_LAUNCH(EPI_SUB_MUL_ADD, false);
+        else PHA_FUSED_LAUNCH(EPI_NONE, false);
+    }
+#undef PHA_FUSED_LAUNCH
+}
+
+#endif
+
 int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stride, const NttRange &r, int epi,
                 const Epilogue &ep, hipStream_t st, int phases = 3) {
     if (!r.active || !polys) return PHA_OK;
     const NttTables T = ctx->fwd_tables();
     NttRange rr = r;
+#ifdef PHA_EXPERIMENT_SINGLE_LAUNCH
+    const size_t tiles = ctx->n >> kTileLog;
+    if (ctx->fused && phases == 3 && !T.split && ctx->plan.s1 == 8 && ctx->plan.s2 == 8 && r.active * polys <= kFusedMaxUnits) {
+        set_placement(rr.lm, false, polys);
+        const size_t tasks = 2 * static_cast<size_t>(r.active) * polys * tiles;
+        const dim3 grid(static_cast<uint32_t>(std::min<size_t>(tasks, static_cast<size_t>(ctx->num_cus) * ctx->fused_wgs)));
+        launch_fused<8, 4, 8, 4>(ctx->narrow, epi, grid, st, data, poly_stride, T, rr.lm, ep, FusedArgs{ctx->fused_ctl.p, kFusedQueues, static_cast<uint32_t>(ctx->fused_depth), static_cast<uint32_t>(ctx->fused >> 1)});
+        return check_launch("forward NTT (single launch)");
+    }
+#endif
     const bool xcd = use_xcd_map(ctx, r.active, polys, ctx->n >> kTileLog);
     set_placement(rr.lm, xcd, polys);
     const dim3 grid(ntt_grid_blocks(xcd, r.active, polys, ctx->n >> kTileLog));
@@ -1256,6 +1293,13 @@ int pha_context_create(int log_n, const uint64_t *moduli_QP, size_t size_QP, siz
             return e && *e ? static_cast<uint32_t>(atoi(e)) : dflt;
         };
         ctx->xcd_map = env_u("PHA_XCD_MAP", 1) ? 1u : 0u;
+#ifdef PHA_EXPERIMENT_SINGLE_LAUNCH
+        ctx->fused = static_cast<int>(env_u("PHA_FUSED_NTT", 0));
+        ctx->fused_wgs = std::max(1, std::min(8, static_cast<int>(env_u("PHA_FUSED_WGS", 4))));
+        ctx->fused_depth = std::max(1, static_cast<int>(env_u("PHA_FUSED_DEPTH", 4)));
+        HIP_TRY(ctx->fused_ctl.alloc(kCtlWords));
+        HIP_TRY(hipMemset(ctx->fused_ctl.p, 0, kCtlWords * sizeof(uint32_t)));
+#endif
         int dev = 0;
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDevice(&dev));
@@ -1431,6 +1475,30 @@ int pha_ntt_launch_phase(pha_context *ctx, uint64_t *inout, size_t polys, size_t
                             as_stream(stream), mask);
     return ntt_forward(ctx, inout, polys, poly_stride_limbs * ctx->n, r, EPI_NONE, Epilogue{}, as_stream(stream), mask);
 }
+
+#ifdef PHA_EXPERIMENT_SINGLE_LAUNCH
+int pha_ntt_single_launch_depth(pha_context *ctx, int depth) {
+    REQUIRE_CTX(true);
+    if (depth < 1) return fail(PHA_ERR_INVALID_ARGUMENT, "depth must be at least 1");
+    ctx->fused_depth = depth;
+    return PHA_OK;
+}
+
+int pha_ntt_single_launch(pha_context *ctx, int enable, int wgs_per_cu) {
+    REQUIRE_CTX(true);
+    if (wgs_per_cu < 1 || wgs_per_cu > 8) return fail(PHA_ERR_INVALID_ARGUMENT, "workgroups per CU must be 1..8");
+    ctx->fused = enable;      // bit 0: on; higher bits: FusedArgs::debug (timing experiments)
+    ctx->fused_wgs = wgs_per_cu;
+    return PHA_OK;
+}
+
+int pha_ntt_single_launch_status(pha_context *ctx, uint32_t *timed_out) {
+    REQUIRE_CTX(timed_out);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(timed_out, ctx->fused_ctl.p + kCtlError, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return PHA_OK;
+}
+#endif
 
 int pha_ntt_block_placement(pha_context *ctx, int limb_to_xcd) {
     REQUIRE_CTX(true);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
@@ -17,6 +18,8 @@ __global__ __launch_bounds__(256) void alu_kernel(uint64_t *out, uint64_t seed) 
     uint32_t b = static_cast<uint32_t>(seed) | 1u;
     uint64_t w = seed * 0x9E3779B97F4A7C15ull | 1ull;
     double fa[ILP];
+    const double fq = 1125899906826241.0 + static_cast<double>(seed & 1), fqinv = 1.0 / fq, fw = 0.37 * fq + static_cast<double>(seed & 3),
+                 fwq = fw * fqinv;
 #pragma unroll
     for (int i = 0; i < ILP; i++) { a[i] = seed + threadIdx.x * 7 + i * 1315423911ull + blockIdx.x; fa[i] = 1.0 + i + threadIdx.x; }
     for (int it = 0; it < ITERS; it++) {
@@ -32,6 +35,22 @@ __global__ __launch_bounds__(256) void alu_kernel(uint64_t *out, uint64_t seed) 
             if (OP == 7) a[i] = a[i] + w;                                                                        // 64-bit add
             if (OP == 8) a[i] = static_cast<uint32_t>(a[i]) + b;                                                 // 32-bit add
             if (OP == 9) a[i] = __mul24(static_cast<int>(a[i]), static_cast<int>(b));                             // v_mul_i32_i24
+            if (OP == 10) fa[i] = fa[i] * 1.0000001;                                                             // v_mul_f64
+            if (OP == 11) fa[i] = fa[i] + 0.4999;                                                                // v_add_f64
+            if (OP == 12) fa[i] = __builtin_rint(fa[i]) + 0.4999;                                                // v_rndne_f64 + v_add_f64
+            if (OP == 13) {  // the FpField modular product as shipped: mul, fma, mul, rndne, fma, add
+                const double h = fa[i] * fw, l = __builtin_fma(fa[i], fw, -h), c = __builtin_rint(fa[i] * fwq);
+                fa[i] = __builtin_fma(-c, fq, h) + l;
+            }
+            if (OP == 14) {  // quotient rounded by adding and subtracting 1.5 * 2^52: mul, fma, fma, add, fma, add
+                const double h = fa[i] * fw, l = __builtin_fma(fa[i], fw, -h);
+                const double c = __builtin_fma(fa[i], fwq, 6755399441055744.0) - 6755399441055744.0;
+                fa[i] = __builtin_fma(-c, fq, h) + l;
+            }
+            if (OP == 15) {  // quotient from h (no w/q companion): mul, fma, mul, rndne, fma, add
+                const double h = fa[i] * fw, l = __builtin_fma(fa[i], fw, -h), c = __builtin_rint(h * fqinv);
+                fa[i] = __builtin_fma(-c, fq, h) + l;
+            }
         }
     }
     uint64_t r = 0;
@@ -96,6 +115,13 @@ int main(int argc, char **argv) {
     run_alu<7>("add64", d_out, 1);
     run_alu<8>("add32", d_out, 1);
     run_alu<9>("v_mul_i32_i24", d_out, 1);
+    run_alu<10>("v_mul_f64", d_out, 1);
+    run_alu<11>("v_add_f64", d_out, 1);
+    run_alu<12>("v_rndne_f64 + v_add_f64", d_out, 2);
+    run_alu<13>("fp64 modmul (rndne), 6 ops", d_out, 6);
+    run_alu<14>("fp64 modmul (magic), 6 ops", d_out, 6);
+    run_alu<15>("fp64 modmul (q from h), 6 ops", d_out, 6);
+    if (argc == 1 && getenv("UBENCH_ALU_ONLY")) return 0;
 
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
