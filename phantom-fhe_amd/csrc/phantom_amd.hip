@@ -884,23 +884,41 @@ int lp_modup_finish(pha_context *ctx, LevelTool *lt, uint64_t *t_mod_up, const u
             PHA_TRY(check_launch("modup_single_p"));
         }
     } else {
-        for (size_t d = 0; d < lt->beta; d++) {
-            const size_t s = d * alpha, e = std::min(s + alpha, size_Ql), len = e - s;
-            uint64_t *dst = t_mod_up + d * size_QlP * n;
-            // owned output limbs that are not the digit's own: at most two runs in Q_l, one in P
-            const size_t runs[3][2] = {{w.q0, std::min(w.q0 + w.qc, s)}, {std::max(w.q0, e), w.q0 + w.qc}, {win[1][0], win[1][1]}};
-            for (const auto &run : runs) {
-                if (run[0] >= run[1]) continue;
-                const size_t row = run[0] < s ? run[0] : run[0] - len, cnt = run[1] - run[0];
-                PHA_TRY(launch_bconv(ctx, dst + run[0] * n, c2_coeff + s * n, lt->modup_matrix[d].p + row * len,
-                                     lt->modup_obase_tidx[d].p + row, static_cast<uint32_t>(len), static_cast<uint32_t>(cnt),
-                                     static_cast<uint32_t>(cnt), 0, 1, BconvBatch{}, st));
+        // the launches of do_modup, restricted to the outputs (and own-limb copies) inside this rank's windows
+        const uint32_t own[4] = {static_cast<uint32_t>(win[0][0]), static_cast<uint32_t>(win[0][1]), static_cast<uint32_t>(win[1][0]),
+                                 static_cast<uint32_t>(win[1][1])};
+        auto owned = [&](BconvBatch bt) {
+            bt.own_set = 1;
+            for (int i = 0; i < 4; i++) bt.own[i] = own[i];
+            return bt;
+        };
+        if (lt->uniform_digits) {
+            const uint32_t obase = static_cast<uint32_t>(size_QlP - alpha);
+            BconvBatch bt{size_QlP * n, alpha * n, static_cast<size_t>(obase) * alpha, obase,
+                          static_cast<uint32_t>(alpha), c2_ntt, alpha * n, 0, 0, 0};
+            PHA_TRY(launch_bconv(ctx, t_mod_up, c2_coeff, lt->modup_matrix_all.p, lt->modup_tidx_all.p,
+                                 static_cast<uint32_t>(alpha), obase, 0, static_cast<uint32_t>(alpha),
+                                 static_cast<uint32_t>(lt->beta), owned(bt), st));
+        } else {
+            for (size_t d = 0; d < lt->beta; d++) {
+                const size_t s = d * alpha, e = std::min(s + alpha, size_Ql), len = e - s;
+                BconvBatch bt{0, 0, 0, 0, 0, c2_ntt + s * n, 0, 0, 0, 0};
+                PHA_TRY(launch_bconv(ctx, t_mod_up + d * size_QlP * n, c2_coeff + s * n, lt->modup_matrix[d].p,
+                                     lt->modup_obase_tidx[d].p, static_cast<uint32_t>(len),
+                                     static_cast<uint32_t>(size_QlP - len), static_cast<uint32_t>(s),
+                                     static_cast<uint32_t>(len), 1, owned(bt), st));
             }
-            // the digit's own limbs stay in NTT form (src/rns_bconv.cu:522-528)
-            const size_t a = std::max(w.q0, s), b = std::min(w.q0 + w.qc, e);
-            if (a < b)
-                HIP_TRY(hipMemcpyAsync(dst + a * n, c2_ntt + a * n, (b - a) * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
         }
+    }
+    if (w.qc && w.pc == alpha && w.q0 + w.qc == size_Ql) {
+        // the Q window ends where the (whole) P window begins, e.g. a single rank: one transform over both, the special
+        // limbs on the key-level tables (a LimbMap addresses the special limbs from the end of P, so a partial P window
+        // keeps its own launch)
+        NttRange r;
+        PHA_TRY(make_range(ctx, w.qc + w.pc, w.q0, ctx->size_QP, w.pc, 0, 0, r));
+        r.lm.digit_alpha = static_cast<uint32_t>(alpha);
+        r.lm.digit_limit = static_cast<uint32_t>(size_Ql);
+        return ntt_forward(ctx, t_mod_up, lt->beta, size_QlP * n, r, EPI_NONE, Epilogue{}, st);
     }
     if (w.qc) {
         NttRange r;
@@ -921,7 +939,11 @@ int lp_inner_prod(pha_context *ctx, LevelTool *lt, uint64_t *cx, const uint64_t 
                   const LimbWindow &w, hipStream_t st) {
     const uint32_t n = static_cast<uint32_t>(ctx->n);
     const uint32_t size_QlP = static_cast<uint32_t>(lt->size_Ql + ctx->size_P);
-    const size_t win[2][2] = {{w.q0, w.qc}, {lt->size_Ql + w.p0, w.pc}};
+    size_t win[2][2] = {{w.q0, w.qc}, {lt->size_Ql + w.p0, w.pc}};
+    if (w.qc && w.pc && w.q0 + w.qc == lt->size_Ql && w.p0 == 0) {  // adjacent windows: one launch
+        win[0][1] = w.qc + w.pc;
+        win[1][1] = 0;
+    }
     for (const auto &lw : win) {
         if (!lw[1]) continue;
         hipLaunchKernelGGL(key_switch_inner_prod_kernel, dim3(static_cast<uint32_t>(lw[1]) * (n / 512)), dim3(256), 0, st, cx,

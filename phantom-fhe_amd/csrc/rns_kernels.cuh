@@ -29,7 +29,15 @@ struct BconvBatch {
     // not in limb order: limb-parallel moddown); register-path kernels only (ibase <= 16)
     uint32_t in_rows_set;
     uint32_t in_row[16];
+    // own_set != 0: only the outputs whose buffer limb jo lies in [own[0], own[1]) or [own[2], own[3]) are computed, and
+    // only those of the digit's own limbs are copied (limb-parallel modup: a rank's Q window and its P window)
+    uint32_t own_set;
+    uint32_t own[4];
 };
+
+__device__ __forceinline__ bool bconv_owned(const BconvBatch &bt, uint32_t jo) {
+    return !bt.own_set || (jo >= bt.own[0] && jo < bt.own[1]) || (jo >= bt.own[2] && jo < bt.own[3]);
+}
 
 __device__ __forceinline__ void bconv_batch_offsets(const BconvBatch &bt, uint32_t z, uint64_t *__restrict__ &dst,
                                                     const uint64_t *__restrict__ &y, const uint64_t *__restrict__ &matrix,
@@ -81,19 +89,26 @@ __global__ __launch_bounds__(256) void bconv_matmul_kernel(uint64_t *__restrict_
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     const uint64_t *src;
     bconv_batch_offsets(bt, blockIdx.z, dst, y, matrix, obase_tidx, skip_start, src);
+    const uint32_t j0 = blockIdx.y * limbs_per_block;
+    const uint32_t j1 = min(j0 + limbs_per_block, obase_size);
+    if (bt.own_set) {   // a workgroup none of whose outputs (or copies) this rank owns has nothing to read
+        bool any = src != nullptr && blockIdx.y == 0 && skip_start < bt.own[1] && skip_start + IB > bt.own[0];
+        for (uint32_t j = j0; j < j1 && !any; j++) any = bconv_owned(bt, j + (j >= skip_start ? skip_len : 0));
+        if (!any) return;
+    }
     uint64_t in[IB];
 #pragma unroll
     for (int i = 0; i < IB; i++) in[i] = y[static_cast<size_t>(bt.in_rows_set ? bt.in_row[i] : i) * n + k];
     if (src != nullptr && blockIdx.y == 0) {
 #pragma unroll
-        for (int i = 0; i < IB; i++) dst[static_cast<size_t>(skip_start + i) * n + k] = src[static_cast<size_t>(i) * n + k];
+        for (int i = 0; i < IB; i++)
+            if (bconv_owned(bt, skip_start + i)) dst[static_cast<size_t>(skip_start + i) * n + k] = src[static_cast<size_t>(i) * n + k];
     }
-    const uint32_t j0 = blockIdx.y * limbs_per_block;
-    const uint32_t j1 = min(j0 + limbs_per_block, obase_size);
     for (uint32_t j = j0; j < j1; j++) {
+        const uint32_t jo = j + (j >= skip_start ? skip_len : 0);
+        if (!bconv_owned(bt, jo)) continue;
         const u128_t acc = dot_residues<IB>(in, matrix + static_cast<size_t>(j) * IB);
         const DModulus m = obase_mod[obase_tidx[j]];
-        const uint32_t jo = j + (j >= skip_start ? skip_len : 0);
         dst[static_cast<size_t>(jo) * n + k] = barrett128(acc, m);
     }
 }
@@ -148,16 +163,17 @@ __global__ __launch_bounds__(256) void bconv_matmul_generic_kernel(uint64_t *dst
     bconv_batch_offsets(bt, blockIdx.z, dst, y, matrix, obase_tidx, skip_start, src);
     if (src != nullptr && blockIdx.y == 0) {
         for (uint32_t i = 0; i < ibase_size; i++)
-            dst[static_cast<size_t>(skip_start + i) * n + k] = src[static_cast<size_t>(i) * n + k];
+            if (bconv_owned(bt, skip_start + i)) dst[static_cast<size_t>(skip_start + i) * n + k] = src[static_cast<size_t>(i) * n + k];
     }
     const uint32_t j0 = blockIdx.y * limbs_per_block;
     const uint32_t j1 = min(j0 + limbs_per_block, obase_size);
     for (uint32_t j = j0; j < j1; j++) {
+        const uint32_t jo = j + (j >= skip_start ? skip_len : 0);
+        if (!bconv_owned(bt, jo)) continue;
         const uint64_t *row = matrix + static_cast<size_t>(j) * ibase_size;
         u128_t acc = {0, 0};
         for (uint32_t i = 0; i < ibase_size; i++) add128(acc, mul64x64(y[static_cast<size_t>(i) * n + k], row[i]));
         const DModulus m = obase_mod[obase_tidx[j]];
-        const uint32_t jo = j + (j >= skip_start ? skip_len : 0);
         dst[static_cast<size_t>(jo) * n + k] = barrett128(acc, m);
     }
 }
