@@ -13,3 +13,19 @@ ct1, ct2 = rnd(3, size_q), rnd(2, size_q)
 for _ in range(int(os.environ.get("REPS", "60"))):
     ctx.multiply_and_relin_inplace(1, ct1, ct2, evk)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+reps = 300
+e0.record()
+for _ in range(reps):
+    ctx.multiply_and_relin_inplace(1, ct1, ct2, evk)
+e1.record()
+e1.synchronize()
+print(f"PHA_KS_OVERLAP={os.environ.get('PHA_KS_OVERLAP', '1')}: HMult + relin {1e3 * e0.elapsed_time(e1) / reps:.1f} us", flush=True)
+elt = pha.galois_elt_from_step(16, 1)
+ct = rnd(2, size_q)
+e0.record()
+for _ in range(reps):
+    ctx.apply_galois_inplace(1, ct, elt, evk)
+e1.record()
+e1.synchronize()
+print(f"   rotate {1e3 * e0.elapsed_time(e1) / reps:.1f} us", flush=True)
