@@ -28,6 +28,11 @@ def main():
     ap.add_argument("--slim", action="store_true", help="SlotToCoeff first, on the last levels (needs --transform fft)")
     ap.add_argument("--s2c-groups", type=int, default=0, help="levels of SlotToCoeff (default: --groups)")
     ap.add_argument("--evalmod-bits", type=int, default=0, help="EvalMod working scale / primes (default: delta-bits)")
+    ap.add_argument("--chain", default="", help="explicit Q chain, bottom first, e.g. 54,48x16,54x14 (the reference's "
+                    "tests/bootstrapping_test.cu:180-185: logq, remaining_level x logp, boot_level x logq)")
+    ap.add_argument("--K", type=int, default=0)
+    ap.add_argument("--r", type=int, default=0)
+    ap.add_argument("--degree", type=int, default=31)
     args = ap.parse_args()
     n = 1 << args.log_n
     d = args.delta_bits
@@ -39,6 +44,11 @@ def main():
         q_bits = [d + 10] + [d] * args.extra_levels + [d] * g2 + evalmod + [args.c2s_bits or min(60, d + 8)] * g
     else:
         q_bits = [d + 10] + [d] * args.extra_levels + [d] + evalmod + [d, min(60, d + 18)]
+    if args.chain:
+        q_bits = []
+        for part in args.chain.split(","):
+            bits, _, rep = part.partition("x")
+            q_bits += [int(bits)] * int(rep or 1)
     while len(q_bits) % args.alpha:
         q_bits.insert(1, d)
     mods = pha.coeff_modulus_create(n, q_bits + [args.special_bits] * args.alpha)
@@ -46,7 +56,8 @@ def main():
     sk = ctx.gen_secretkey(21, hamming_weight=192 if args.log_n >= 15 else 32)
     ev = GpuEvaluator(pha, ctx, sk, args.slots)
     t0 = time.perf_counter()
-    bs = Bootstrapper(ev, K=25 if args.log_n >= 15 else 12, r=3 if args.log_n < 15 else 4, degree=31, delta=2.0 ** e, msg_scale=2.0 ** d,
+    bs = Bootstrapper(ev, K=args.K or (25 if args.log_n >= 15 else 12), r=args.r or (3 if args.log_n < 15 else 4), degree=args.degree,
+                      delta=2.0 ** e, msg_scale=2.0 ** d,
                       transform=args.transform, c2s_groups=args.groups, s2c_groups=args.s2c_groups or args.groups, slim=args.slim)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
