@@ -57,7 +57,7 @@ BUTTERFLIES_PER_LIMB = (N // 2) * LOG_N
 INT32_MUL_PEAK = 31.03e12    # v_mad_u64_u32
 FP64_PEAK = 36.74e12         # v_fma_f64
 MUL32_PER_INT_BUTTERFLY = 9      # csrc/modarith.cuh: approximate-quotient Shoup product
-FP64_PER_FP_BUTTERFLY = 10.3     # csrc/modarith.cuh FpField: 659 FP64 instructions per 64 butterflies in the ISA
+FP64_PER_FP_BUTTERFLY = 10.0     # csrc/modarith.cuh FpField: 639 FP64 instructions per 64 butterflies in the ISA (column kernel)
 
 
 def parse(argv=None):
