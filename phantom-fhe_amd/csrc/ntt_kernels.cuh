@@ -102,6 +102,9 @@ enum : int { EPI_NONE = 0, EPI_SUB_MUL = 1, EPI_SUB_MUL_ADD = 2, EPI_SCALE = 3 }
 #ifndef PHA_SC1_STORES
 #define PHA_SC1_STORES 2
 #endif
+#ifndef PHA_EPI_PREFETCH
+#define PHA_EPI_PREFETCH 2
+#endif
 typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
 // threadIdx.x as a value the optimiser cannot see through: inside a persistent loop (ntt_fused.cuh) everything derived
 // from the lane index would otherwise be hoisted out of the loop (300 VGPRs of addresses and LDS offsets, spilled)
@@ -468,6 +471,20 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, const uint64_t (&ra
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) lds[lds_row(e0 + j)] = F::raw(f.canon_fwd(x[j]));
     }
+#if PHA_EPI_PREFETCH
+    // The epilogue's operand streams are requested here, where the butterfly registers are dead and the workgroup is
+    // about to wait at the barrier, instead of after it (measured: profiles/r2c_ab_epilogue_prefetch.log)
+    ulonglong2 pre_s[8], pre_a[8];
+    if (EPI != EPI_NONE) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t e = (i * kThreads + t) * 2;
+            pre_s[i] = *reinterpret_cast<const ulonglong2 *>(sub + e);
+            if (PHA_EPI_PREFETCH >= 2 && EPI == EPI_SUB_MUL_ADD && addend != nullptr)
+                pre_a[i] = *reinterpret_cast<const ulonglong2 *>(addend + e);
+        }
+    }
+#endif
     __syncthreads();
 
     const typename F::twt c = f.make_cst(cst, cst_shoup);
@@ -480,11 +497,19 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, const uint64_t (&ra
             // (cx - NTT(delta)) * PInv mod q  (src/ntt/ntt_moddown.cu:209-214,
             // include/uintmodmath.cuh:234-242); same shape for rescale (src/rns.cu:1138-1155)
             // (fetching these operands a pass ahead was measured: no gain, and 64 more VGPRs)
+#if PHA_EPI_PREFETCH
+            const ulonglong2 s = pre_s[i];
+#else
             const ulonglong2 s = *reinterpret_cast<const ulonglong2 *>(sub + e);
+#endif
             v.x = f.to_u64(f.sub_mul(v0, s.x, c));
             v.y = f.to_u64(f.sub_mul(v1, s.y, c));
             if (EPI == EPI_SUB_MUL_ADD && addend != nullptr) {
+#if PHA_EPI_PREFETCH >= 2
+                const ulonglong2 a = pre_a[i];
+#else
                 const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(addend + e);
+#endif
                 v.x = csub(v.x + a.x, q);
                 v.y = csub(v.y + a.y, q);
             }
