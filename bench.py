@@ -124,7 +124,8 @@ def dist_setup(backend, device_bound=True):
     if world > 1:
         import torch
         import torch.distributed as dist
-        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" and device_bound else {}
+        kw = ({"device_id": torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))}
+              if backend == "nccl" and device_bound else {})
         dist.init_process_group(backend, **kw)
     return rank, world, local_rank, dist
 
@@ -498,9 +499,10 @@ def main(argv=None):
 
         import phantom_fhe_amd as pha
 
-        rank, world, local_rank, dist = dist_setup(args.backend)
         assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-        torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+        # this rank's GPU is current before the process group (RCCL communicator, barriers) comes up on it
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+        rank, world, local_rank, dist = dist_setup(args.backend)
         out = {2: run_config2, 3: run_config3, 4: run_config4}[args.config](args, torch, pha, rank, world, dist)
     if rank == 0:
         print(json.dumps(out), flush=True)
