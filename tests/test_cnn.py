@@ -232,3 +232,19 @@ def test_relu_by_height_equals_the_recursion():
     b = relu.evaluate(ev, ct)
     assert a.level == b.level and abs(a.scale / b.scale - 1) < 1e-12
     assert np.abs(ev.decrypt_decode(a, 1 << LOGN) - ev.decrypt_decode(b, 1 << LOGN)).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_resnet20_cifar10_at_the_stated_size():
+    """BASELINE configs[4] at its stated size (N = 2^16, ResNet-20, 18 bootstrappings; tools/bench_resnet20.py builds the
+    chain, the keys and the network from tests/golden/resnet20_cifar10.npz): the encrypted logits against the plain network
+    with the same ReLU polynomial, and the same class as the exact network.  ~55 GiB of rotation keys."""
+    import torch
+    if torch.cuda.get_device_properties(0).total_memory < 120 * 2 ** 30:
+        pytest.skip("needs ~70 GiB of device memory")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_resnet20
+    res = bench_resnet20.run(bench_resnet20.parse(["--reps", "1"]))
+    assert res["max_logit_error_vs_plain_same_relu"] < 5e-3, res
+    assert res["argmax"] == res["argmax_plain"], res
+    torch.cuda.empty_cache()

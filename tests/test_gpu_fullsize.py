@@ -72,3 +72,26 @@ def test_config3_keyswitch_vs_oracle(gpu, pha, orc, cfg3):
     d_rot = pha.to_device(ct1)
     ctx.apply_galois_inplace(1, d_rot, 5, evk)
     assert (pha.to_host(d_rot) == rot_ref).all()
+
+
+def test_config4_rotate_64_ciphertexts_full_size(gpu, pha, cfg3):
+    """BASELINE configs[3] at its stated size: rotation of 64 independent ciphertexts (N = 2^16, 36 + 12 limbs), in batches
+    of 16 as bench.py --config 4 issues them.  Property: every ciphertext of a batch equals the single-ciphertext
+    pha_apply_galois_inplace of the same input bit for bit (that entry point is compared with the oracle at this size in
+    test_config3_keyswitch_vs_oracle).  The keys are uniform stand-ins, which is enough for the arithmetic identity of the
+    two code paths."""
+    import torch
+    ctx, o = cfg3
+    size_ql, total, batch = 36, 64, 16
+    g = torch.Generator(device="cuda").manual_seed(11)
+    lo = int(o.moduli.min())
+    evk = pha.EvalKey([torch.randint(0, lo, (2, 48, N), dtype=torch.int64, device="cuda", generator=g) for _ in range(3)])
+    elt = pha.galois_elt_from_step(16, 1)
+    for b0 in range(0, total, batch):
+        cts = torch.randint(0, lo, (batch, 2, size_ql, N), dtype=torch.int64, device="cuda", generator=g)
+        out = ctx.apply_galois_batched(1, cts, elt, evk)
+        assert out.shape == cts.shape
+        for i in range(batch):
+            one = cts[i].clone()
+            ctx.apply_galois_inplace(1, one, elt, evk)
+            assert torch.equal(out[i], one), f"ciphertext {b0 + i} of the batched rotation differs from the single call"
