@@ -60,7 +60,8 @@ int pha_host_level_constants(const uint64_t *moduli_QP, size_t size_QP, size_t s
 
 /* ---- context: PhantomContext + DNTTTable + per-level DRNSTool (src/context.cu:120-290) --- */
 /* moduli_QP = key-level coeff_modulus (Q then P); size_P = special_modulus_size
- * (include/util/encryptionparams.h:375, default 1).  Uses the current HIP device. */
+ * (include/util/encryptionparams.h:375, default 1).  Uses the current HIP device.  log_n = 11 .. 17, the degrees of
+ * SAMPLE_SIZE (include/ntt.cuh:16-24); any other: PHA_ERR_INVALID_ARGUMENT ("unsupported polynomial degree"). */
 int pha_context_create(int log_n, const uint64_t *moduli_QP, size_t size_QP, size_t size_P, pha_context **out);
 void pha_context_destroy(pha_context *ctx);
 size_t pha_context_n(const pha_context *ctx);

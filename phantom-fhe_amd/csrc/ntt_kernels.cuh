@@ -717,6 +717,98 @@ __global__ PHA_NTT_BOUNDS void intt_col_kernel(uint64_t *data, size_t poly_strid
 }
 
 // ---------------------------------------------------------------------------------------------
+// N = 2^11 (the smallest SAMPLE_SIZE case of the reference, include/ntt.cuh:16-24; no CKKS parameter set of its tests
+// uses it): the polynomial is smaller than a tile, so one workgroup transforms a whole limb inside LDS, one stage
+// per barrier, on the integer path (such a context keeps every table in the {w, Shoup} form).  Same stage order,
+// twiddle indexing (tw[m + k]) and epilogues as the tiled kernels; speed is not a goal here.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSmallN = 2048;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void small_fntt_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm, Epilogue ep) {
+    __shared__ uint64_t lds[kSmallN];
+    const uint32_t n = 1u << T.log_n, poly = blockIdx.x % lm.polys, li = blockIdx.x / lm.polys, t0 = threadIdx.x;
+    uint32_t twr, tidx;
+    if (!resolve_limb(lm, poly, li, twr, tidx)) return;
+    const DModulus mod = T.mod[tidx];
+    const IntField<false> f(mod);
+    const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
+    const size_t limb_off = static_cast<size_t>(twr) * n;
+    uint64_t *limb = data + poly * poly_stride + limb_off;
+    for (uint32_t i = t0; i < n; i += 256) lds[i] = limb[i];
+    uint32_t log_t = T.log_n - 1;
+    for (uint32_t m = 1; m < n; m <<= 1, log_t--) {
+        __syncthreads();
+        for (uint32_t idx = t0; idx < n / 2; idx += 256) {
+            const uint32_t k = idx >> log_t, j = idx & ((1u << log_t) - 1), a = ((2 * k) << log_t) + j, b = a + (1u << log_t);
+            uint64_t x = lds[a], y = lds[b];
+            f.template ct<0>(x, y, tw[m + k]);
+            lds[a] = x;
+            lds[b] = y;
+        }
+    }
+    __syncthreads();
+    uint64_t *out = limb;
+    const uint64_t *sub = nullptr, *addend = nullptr;
+    tw_t c{0, 0};
+    if (EPI != EPI_NONE) {
+        out = ep.out + poly * ep.out_poly_stride + limb_off;
+        sub = ep.sub + poly * ep.sub_poly_stride + limb_off;
+        if (EPI == EPI_SUB_MUL_ADD && (ep.addend_every == 0 || poly % ep.addend_every == 0))
+            addend = ep.addend + poly * ep.out_poly_stride + limb_off;
+        c = f.make_cst(ep.cst[twr - ep.cst_limb0], ep.cst_shoup[twr - ep.cst_limb0]);
+    }
+    for (uint32_t i = t0; i < n; i += 256) {
+        uint64_t v = f.canon_fwd(lds[i]);
+        if (EPI != EPI_NONE) {
+            v = f.sub_mul(v, sub[i], c);
+            if (EPI == EPI_SUB_MUL_ADD && addend != nullptr) v = csub(v + addend[i], mod.value);
+        }
+        out[i] = v;
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void small_intt_kernel(uint64_t *out, const uint64_t *in, size_t poly_stride, NttTables T,
+                                                         LimbMap lm, Epilogue ep) {
+    __shared__ uint64_t lds[kSmallN];
+    const uint32_t n = 1u << T.log_n, poly = blockIdx.x % lm.polys, li = blockIdx.x / lm.polys, t0 = threadIdx.x;
+    uint32_t twr, tidx;
+    if (!resolve_limb(lm, poly, li, twr, tidx)) return;
+    const DModulus mod = T.mod[tidx];
+    const IntField<false> f(mod);
+    const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
+    const uint64_t *src = in + poly * poly_stride + static_cast<size_t>(twr) * n;
+    uint64_t *dst = out + inv_out_offset(lm, poly, poly_stride, twr, n);
+    for (uint32_t i = t0; i < n; i += 256) lds[i] = src[i];
+    uint32_t log_t = 0;
+    for (uint32_t m = n >> 1; m >= 2; m >>= 1, log_t++) {
+        __syncthreads();
+        for (uint32_t idx = t0; idx < n / 2; idx += 256) {
+            const uint32_t k = idx >> log_t, j = idx & ((1u << log_t) - 1), a = ((2 * k) << log_t) + j, b = a + (1u << log_t);
+            uint64_t x = lds[a], y = lds[b];
+            f.gs(x, y, tw[m + k]);
+            lds[a] = x;
+            lds[b] = y;
+        }
+    }
+    __syncthreads();
+    const tw_t n_inv = f.make_cst(T.n_inv[tidx], T.n_inv_shoup[tidx]);
+    tw_t c{0, 0};
+    if (EPI == EPI_SCALE) c = f.make_cst(ep.cst[twr - ep.cst_limb0], ep.cst_shoup[twr - ep.cst_limb0]);
+    for (uint32_t j = t0; j < n / 2; j += 256) {   // last stage (m = 1) with N^-1, then the optional scale
+        uint64_t x = lds[j], y = lds[j + n / 2];
+        f.gs_last(x, y, tw[1], n_inv);
+        if (EPI == EPI_SCALE) {
+            x = f.scale(x, c);
+            y = f.scale(y, c);
+        }
+        dst[j] = x;
+        dst[j + n / 2] = y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // N = 2^17: the outermost radix-2 stage (m = 1, pairs N/2 apart) as an element-wise kernel on canonical
 // residues; Barrett products, so the same code serves integer and FP64 limbs.  One workgroup = 4096 pairs.
 // ---------------------------------------------------------------------------------------------

@@ -76,15 +76,17 @@ inline const char *capture_hint(hipError_t e) {
 struct NttPlan {
     int s1, ra1, s2, ra2;
     int split;  // 1: the outermost radix-2 stage runs in its own kernel (N = 2^17)
+    int small;  // 1: the polynomial is smaller than a tile; one workgroup per limb, all stages in LDS (N = 2^11)
 };
 bool plan_for(int log_n, NttPlan &p) {
     switch (log_n) {
-        case 12: p = {6, 3, 6, 3, 0}; return true;
-        case 13: p = {6, 3, 7, 4, 0}; return true;
-        case 14: p = {7, 4, 7, 4, 0}; return true;
-        case 15: p = {7, 4, 8, 4, 0}; return true;
-        case 16: p = {8, 4, 8, 4, 0}; return true;
-        case 17: p = {8, 4, 8, 4, 1}; return true;
+        case 11: p = {0, 0, 0, 0, 0, 1}; return true;
+        case 12: p = {6, 3, 6, 3, 0, 0}; return true;
+        case 13: p = {6, 3, 7, 4, 0, 0}; return true;
+        case 14: p = {7, 4, 7, 4, 0, 0}; return true;
+        case 15: p = {7, 4, 8, 4, 0, 0}; return true;
+        case 16: p = {8, 4, 8, 4, 0, 0}; return true;
+        case 17: p = {8, 4, 8, 4, 1, 0}; return true;
         default: return false;
     }
 }
@@ -268,7 +270,7 @@ void to_fp64_records(tw_t *rec, size_t count) {
 int upload_tables(pha_context *ctx) {
     const size_t n = ctx->n, L = ctx->size_QP;
     const int rb = ctx->plan.s2 - ctx->plan.ra2;
-    const size_t stride = (n >> rb) * ((size_t(1) << rb) - 1);
+    const size_t stride = ctx->plan.small ? 0 : (n >> rb) * ((size_t(1) << rb) - 1);   // no last-pass tables for the LDS kernels
     ctx->twD_stride = static_cast<uint32_t>(stride);
     std::vector<tw_t> tw(L * n), itw(L * n), twD(L * stride), itwD(L * stride);
     std::vector<DModulus> mods(L);
@@ -277,8 +279,10 @@ int upload_tables(pha_context *ctx) {
         const LimbTables &t = ctx->host_tables[l];
         interleave(t.tw, t.tw_shoup, tw.data() + l * n);
         interleave(t.itw, t.itw_shoup, itw.data() + l * n);
-        last_pass_order(tw.data() + l * n, n, rb, twD.data() + l * stride);
-        last_pass_order(itw.data() + l * n, n, rb, itwD.data() + l * stride);
+        if (stride) {
+            last_pass_order(tw.data() + l * n, n, rb, twD.data() + l * stride);
+            last_pass_order(itw.data() + l * n, n, rb, itwD.data() + l * stride);
+        }
         if (ctx->limb_is_fp64(l)) {
             to_fp64_records(tw.data() + l * n, n);
             to_fp64_records(itw.data() + l * n, n);
@@ -429,6 +433,18 @@ int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stri
     if (!r.active || !polys) return PHA_OK;
     const NttTables T = ctx->fwd_tables();
     NttRange rr = r;
+    if (ctx->plan.small) {
+        if (!(phases & 1)) return PHA_OK;   // one kernel does the whole transform
+        set_placement(rr.lm, false, polys);
+        const dim3 g(static_cast<uint32_t>(r.active * polys));
+        if (epi == EPI_SUB_MUL)
+            hipLaunchKernelGGL((small_fntt_kernel<EPI_SUB_MUL>), g, dim3(256), 0, st, data, poly_stride, T, rr.lm, ep);
+        else if (epi == EPI_SUB_MUL_ADD)
+            hipLaunchKernelGGL((small_fntt_kernel<EPI_SUB_MUL_ADD>), g, dim3(256), 0, st, data, poly_stride, T, rr.lm, ep);
+        else
+            hipLaunchKernelGGL((small_fntt_kernel<EPI_NONE>), g, dim3(256), 0, st, data, poly_stride, T, rr.lm, ep);
+        return check_launch("forward NTT (N = 2^11)");
+    }
 #ifdef PHA_EXPERIMENT_SINGLE_LAUNCH
     const size_t tiles = ctx->n >> kTileLog;
     if (ctx->fused && phases == 3 && !T.split && ctx->plan.s1 == 8 && ctx->plan.s2 == 8 && r.active * polys <= kFusedMaxUnits) {
@@ -465,6 +481,16 @@ int ntt_backward(pha_context *ctx, uint64_t *out, const uint64_t *in, size_t pol
     NttRange rr = r;
     rr.lm.out_limb0 = static_cast<uint32_t>(out_limb0);
     rr.lm.out_poly_stride = out_poly_stride;
+    if (ctx->plan.small) {
+        if (!(phases & 1)) return PHA_OK;
+        set_placement(rr.lm, false, polys);
+        const dim3 g(static_cast<uint32_t>(r.active * polys));
+        if (epi == EPI_SCALE)
+            hipLaunchKernelGGL((small_intt_kernel<EPI_SCALE>), g, dim3(256), 0, st, out, in, poly_stride, T, rr.lm, ep);
+        else
+            hipLaunchKernelGGL((small_intt_kernel<EPI_NONE>), g, dim3(256), 0, st, out, in, poly_stride, T, rr.lm, ep);
+        return check_launch("inverse NTT (N = 2^11)");
+    }
     const bool xcd = use_xcd_map(ctx, r.active, polys, ctx->n >> kTileLog);
     set_placement(rr.lm, xcd, polys);
     const dim3 grid(ntt_grid_blocks(xcd, r.active, polys, ctx->n >> kTileLog));
@@ -1308,7 +1334,7 @@ int pha_context_create(int log_n, const uint64_t *moduli_QP, size_t size_QP, siz
     ctx->plan = plan;
     ctx->moduli.assign(moduli_QP, moduli_QP + size_QP);
     const char *no_fp = getenv("PHA_DISABLE_FP64");
-    ctx->fp64 = !(no_fp && no_fp[0] == '1');
+    ctx->fp64 = !(no_fp && no_fp[0] == '1') && !plan.small;   // the LDS kernels of N = 2^11 are integer-only
     {
         auto env_u = [](const char *name, uint32_t dflt) {
             const char *e = getenv(name);

@@ -21,7 +21,7 @@ def small(gpu, pha, orc):
     return pha.PhantomContext(12, mods, 2), orc.Oracle(12, mods, 2)
 
 
-@pytest.mark.parametrize("log_n", [12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("log_n", [11, 12, 13, 14, 15, 16, 17])
 def test_ntt_forward_backward_all_sizes(gpu, pha, orc, log_n):
     n = 1 << log_n
     mods = orc.coeff_modulus_create(n, [60, 50, 40, 60])
@@ -74,6 +74,55 @@ def test_n131072_key_switch_rescale_galois(gpu, pha, orc):
     d_out = _dev(pha, np.zeros_like(ct[0]))
     ctx.apply_galois_ntt(_dev(pha, ct[0]), size_ql, elt, d_out)
     assert (_host(pha, d_out) == o.apply_galois_ntt(ct[0], elt)).all()
+    ctx.close()
+
+
+@pytest.mark.parametrize("size_p", [1, 2])
+def test_n2048_every_transform_variant(gpu, pha, orc, size_p):
+    """N = 2^11 (the smallest SAMPLE_SIZE case, include/ntt.cuh:16-24): the polynomial is smaller than a tile, one workgroup
+    transforms a limb inside LDS.  Tables, forward / inverse (in place, out of place, scaled), and through the key switch,
+    rotation and rescale every fused variant (scale epilogue of the modup INTT, digit exclusion, special-modulus indices,
+    moddown and rescale epilogues) against the oracle."""
+    log_n, n = 11, 2048
+    mods = orc.coeff_modulus_create(n, [55, 45, 45, 45] + [56] * size_p)
+    ctx, o = pha.PhantomContext(log_n, mods, size_p), orc.Oracle(log_n, mods, size_p)
+    for which in range(4):
+        assert (ctx.get_table(1, which) == o.table(which, 1)).all()
+    size_ql = 4
+    lim = list(range(size_ql))
+    x = o.uniform_poly(lim, 5)
+    ref = x.copy()
+    o.nwt_forward_inplace(ref, size_ql, 0)
+    d = _dev(pha, x + (np.uint64(3) * o.moduli[:size_ql, None]).astype(np.uint64))     # lazy input
+    ctx.nwt_2d_radix8_forward_inplace(d, size_ql, 0)
+    assert (_host(pha, d) == ref).all()
+    ctx.nwt_2d_radix8_backward_inplace(d, size_ql, 0)
+    assert (_host(pha, d) == x).all()
+    d_out = _dev(pha, np.zeros_like(x))
+    ctx.nwt_2d_radix8_backward(d_out, _dev(pha, ref), size_ql, 0)
+    assert (_host(pha, d_out) == x).all()
+    evk_h, evk_d = _uniform_evk(pha, o, 70)
+    for chain_index in (1, 2):
+        ql = size_ql - (chain_index - 1)
+        lim = list(range(ql))
+        ct = np.stack([o.uniform_poly(lim, 7), o.uniform_poly(lim, 8)])
+        c2 = o.uniform_poly(lim, 6)
+        ct_ref = ct.copy()
+        o.keyswitch_inplace(ql, ct_ref, c2, evk_h)
+        d_ct = _dev(pha, ct)
+        ctx.keyswitch_inplace(chain_index, d_ct, _dev(pha, c2), evk_d)
+        assert (_host(pha, d_ct) == ct_ref).all()
+        rs_ref = o.divide_and_round_q_last_ntt(ql, ct, 2)
+        d_rs = _dev(pha, np.zeros_like(rs_ref))
+        ctx.rescale_to_next(chain_index, _dev(pha, ct), 2, d_rs)
+        assert (_host(pha, d_rs) == rs_ref).all()
+    elt = orc.galois_elt_from_step(log_n, 3)
+    ct = np.stack([o.uniform_poly(list(range(size_ql)), 17), o.uniform_poly(list(range(size_ql)), 18)])
+    rot_ref = np.stack([o.apply_galois_ntt(ct[0], elt), np.zeros_like(ct[1])])
+    o.keyswitch_inplace(size_ql, rot_ref, o.apply_galois_ntt(ct[1], elt), evk_h)
+    d_rot = _dev(pha, ct)
+    ctx.apply_galois_inplace(1, d_rot, elt, evk_d)
+    assert (_host(pha, d_rot) == rot_ref).all()
     ctx.close()
 
 

@@ -86,3 +86,23 @@ def test_bootstrap_at_the_reference_test_parameters(gpu, pha, logp, logq):
     ctx.close()
     torch.cuda.empty_cache()
     assert err.max() < 1e-4 and err.mean() < 2e-5, (err.max(), err.mean())
+
+
+def test_n2048_encrypted_pipeline(gpu, pha):
+    """N = 2^11 end to end (encode, encrypt, multiply + relinearise, rescale, rotate, decrypt, decode): the degree below a
+    transform tile takes the LDS kernels and, for everything else, the ordinary paths at 1024 slots."""
+    from phantom_fhe_amd.ckks import GpuEvaluator
+    n, bits, scale = 2048, [54, 40, 40, 54], 2.0 ** 40
+    ctx = pha.PhantomContext(11, pha.coeff_modulus_create(n, bits), 1)
+    ev = GpuEvaluator(pha, ctx, ctx.gen_secretkey(5), n // 2, seed=300)
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, n // 2) + 1j * rng.uniform(-1, 1, n // 2)
+    y = rng.uniform(-1, 1, n // 2) + 1j * rng.uniform(-1, 1, n // 2)
+    cx, cy = ev.encrypt(ev.encode(x, scale, 1)), ev.encrypt(ev.encode(y, scale, 1))
+    rs = ev.rescale(ev.mul(cx, cy))
+    ev.add_rotation_keys([3], conj=True)
+    rot = ev.rotate(rs, 3)
+    assert np.abs(ev.decrypt_decode(rs) - x * y).max() < 1e-5
+    assert np.abs(ev.decrypt_decode(rot) - np.roll(x * y, -3)).max() < 1e-5
+    assert np.abs(ev.decrypt_decode(ev.conj(cx)) - np.conj(x)).max() < 1e-6
+    ctx.close()
