@@ -258,7 +258,7 @@ int main() {
         try { multiply_inplace(context, r, y, sw); } catch (const std::invalid_argument &) { caught++; }
         try {
             EncryptionParameters bad = parms;
-            bad.set_poly_modulus_degree(2048);
+            bad.set_poly_modulus_degree(1024);       // below the SAMPLE_SIZE list (include/ntt.cuh:16-24)
             PhantomContext c2(bad);
         } catch (const std::invalid_argument &) { caught++; }
         printf("{\"errors_caught\": %d}\n", caught);
