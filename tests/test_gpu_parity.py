@@ -126,6 +126,30 @@ def test_n2048_every_transform_variant(gpu, pha, orc, size_p):
     ctx.close()
 
 
+def test_block_placement_does_not_change_results(gpu, pha, orc):
+    """pha_ntt_block_placement: the limb-to-XCD block map and the tile-interleaved one are two orders of the same work
+    (several polys, a limb count that is not a multiple of 8, a start offset)."""
+    import torch
+    log_n, n = 13, 8192
+    mods = orc.coeff_modulus_create(n, [60] + [45] * 10 + [55] * 2)
+    ctx, o = pha.PhantomContext(log_n, mods, 2), orc.Oracle(log_n, mods, 2)
+    x = np.stack([o.uniform_poly(list(range(13)), 900 + p) for p in range(3)])
+    outs = []
+    for placement in (1, 0):
+        ctx.ntt_block_placement(placement)
+        d = _dev(pha, x)
+        ctx.ntt_forward_batched(d, 3, 13, 11, 1)             # limbs 1..11 of three polys
+        f = d.clone()
+        ctx.ntt_backward_batched(d, 3, 13, 11, 1)
+        assert torch.equal(d, _dev(pha, x))
+        outs.append(f)
+    assert torch.equal(outs[0], outs[1])
+    ref = x[0].copy()
+    o.nwt_forward_inplace(ref, 11, 1)
+    assert (_host(pha, outs[0])[0] == ref).all()
+    ctx.close()
+
+
 def test_forward_tolerates_lazy_inputs(gpu, pha, small):
     ctx, o = small
     x = o.uniform_poly([0], 1)
