@@ -148,3 +148,21 @@ def test_torch_distributed_ranks(gpu, backend, nproc):
                           "--p-bits", "55", "--check"], capture_output=True, text=True, timeout=170, env=env)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     assert out.stdout.count("ok rank") == nproc
+
+
+@pytest.mark.parametrize("config,steps", [(2, 20), (3, 5), (4, 2)])
+def test_bench_legs_with_two_ranks(gpu, config, steps):
+    """bench.py --gpus 2: the script starts its two ranks itself (torch.distributed.run child), both share this GPU and
+    rendezvous over gloo (RCCL refuses two ranks on one device); every leg prints one line with n_gpus = 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", str(config),
+                          "--steps", str(steps), "--warmup", "1"], capture_output=True, text=True, timeout=170, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == steps and line["value"] > 0
+    assert line["scaling"] == ("weak" if config == 2 else "strong")
