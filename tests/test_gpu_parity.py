@@ -150,6 +150,40 @@ def test_block_placement_does_not_change_results(gpu, pha, orc):
     ctx.close()
 
 
+def test_random_batches_against_oracle(gpu, pha, orc):
+    """Seeded sweep over the launch shapes of the batched transforms — polys 1..48 (the block decode divides by the poly
+    count with a multiply-by-reciprocal), limb counts that are and are not multiples of 8, start offsets, both block
+    placements, N = 2^12 and 2^13 — forward against the oracle limb by limb, then the round trip."""
+    import torch
+    rng = np.random.default_rng(2024)
+    for log_n in (12, 13):
+        n = 1 << log_n
+        mods = orc.coeff_modulus_create(n, [60, 50, 45, 40, 50, 50, 45, 60, 50, 50, 45, 50, 50])
+        ctx, o = pha.PhantomContext(log_n, mods, 1), orc.Oracle(log_n, mods, 1)
+        limbs = len(mods)
+        base = np.stack([o.uniform_poly(list(range(limbs)), 3000 + p) for p in range(4)])
+        ref = base.copy()
+        for p in range(4):
+            o.nwt_forward_inplace(ref[p], limbs, 0)
+        for case in range(14):
+            polys = int(rng.choice([1, 2, 3, 5, 7, 8, 16, 31, 48]))
+            count = int(rng.integers(1, limbs + 1))
+            start = int(rng.integers(0, limbs - count + 1))
+            ctx.ntt_block_placement(case & 1)
+            x = np.stack([base[p % 4] for p in range(polys)])
+            d = _dev(pha, x)
+            ctx.ntt_forward_batched(d, polys, limbs, count, start)
+            got = _host(pha, d)
+            for p in range(polys):
+                assert (got[p, start:start + count] == ref[p % 4, start:start + count]).all(), (log_n, polys, count, start, p)
+                untouched = np.ones(limbs, dtype=bool)
+                untouched[start:start + count] = False
+                assert (got[p, untouched] == x[p, untouched]).all(), (log_n, polys, count, start, p)
+            ctx.ntt_backward_batched(d, polys, limbs, count, start)
+            assert torch.equal(d, _dev(pha, x)), (log_n, polys, count, start)
+        ctx.close()
+
+
 def test_forward_tolerates_lazy_inputs(gpu, pha, small):
     ctx, o = small
     x = o.uniform_poly([0], 1)
