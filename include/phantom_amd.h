@@ -128,6 +128,15 @@ int pha_ntt_launch_phase(pha_context *ctx, uint64_t *inout, size_t polys, size_t
  * one XCD; 0 restores the tile-interleaved placement.  A speed setting for A/B measurements; results are identical. */
 int pha_ntt_block_placement(pha_context *ctx, int limb_to_xcd);
 
+/* The single-launch transform (no reference counterpart; the reference's transform is the two grid-stride launches of
+ * src/ntt/fntt_2d.cu:620-653): enable != 0 runs a forward transform of at least `min_units` (poly, limb) pairs as ONE
+ * persistent launch whose column pass hands its result to the row pass inside each XCD's L2 (csrc/ntt_fused.cuh);
+ * `flags` are the FUSED_* experiment switches of that file (0 for production use).  Results are identical either way.
+ * pha_ntt_fused_status synchronises the device and returns the launch error word (0 = none; set when a bounded wait of
+ * the single launch ran out, after which results are invalid) and the number of task queues (XCDs) of the device. */
+int pha_ntt_fused_config(pha_context *ctx, int enable, uint32_t flags, uint32_t min_units);
+int pha_ntt_fused_status(pha_context *ctx, uint32_t *error_word, uint32_t *queues);
+
 /* ---- DRNSTool (include/rns.cuh:155-185); chain_index as in the reference:
  *      1 = first data level (all of Q), k = Q minus its last k-1 primes (src/context.cu:148-174) */
 /* DRNSTool::modup, CKKS branch (src/rns_bconv.cu:530-628): dst[beta][size_QlP][N] */

@@ -65,6 +65,8 @@ SIGNATURES = {
     "pha_ntt_backward_batched": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "pha_ntt_launch_phase": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _int, _int, _vp]),
     "pha_ntt_block_placement": (_int, [_vp, _int]),
+    "pha_ntt_fused_config": (_int, [_vp, _int, _u32, _u32]),
+    "pha_ntt_fused_status": (_int, [_vp, _u32p, _u32p]),
     "pha_modup": (_int, [_vp, _sz, _vp, _vp, _vp]),
     "pha_key_switch_inner_prod": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _vp]),
     "pha_moddown_from_ntt": (_int, [_vp, _sz, _vp, _vp, _vp]),
@@ -337,6 +339,16 @@ class PhantomContext:
 
     def ntt_block_placement(self, limb_to_xcd):
         _check(lib().pha_ntt_block_placement(self._h, int(limb_to_xcd)))
+
+    def ntt_fused_config(self, enable, flags=0, min_units=16):
+        """Single-launch forward transform (csrc/ntt_fused.cuh) on / off; `flags` = its FUSED_* experiment switches."""
+        _check(lib().pha_ntt_fused_config(self._h, int(enable), int(flags), int(min_units)))
+
+    def ntt_fused_status(self):
+        """(error word of the single-launch transform, number of task queues = XCDs); synchronises the device."""
+        e, q = _u32(), _u32()
+        _check(lib().pha_ntt_fused_status(self._h, ctypes.byref(e), ctypes.byref(q)))
+        return e.value, q.value
 
     # DRNSTool ---------------------------------------------------------------------------------
     def modup(self, chain_index, dst, cks):

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libphantom_amd.so")
 SOURCES = ["phantom_amd.hip", "numth.cpp"]
-DEPS = SOURCES + ["modarith.cuh", "ntt_kernels.cuh", "rns_kernels.cuh", "keygen_kernels.cuh", "encoder_kernels.cuh", "numth.hpp",
+DEPS = SOURCES + ["modarith.cuh", "ntt_kernels.cuh", "ntt_fused.cuh", "rns_kernels.cuh", "keygen_kernels.cuh", "encoder_kernels.cuh", "numth.hpp",
                   os.path.join("..", "..", "include", "phantom_amd.h")]
 
 

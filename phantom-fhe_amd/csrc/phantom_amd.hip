@@ -19,9 +19,7 @@
 
 #include "../../include/phantom_amd.h"
 #include "ntt_kernels.cuh"
-#ifdef PHA_EXPERIMENT_SINGLE_LAUNCH  // measured and rejected (profiles/r2c_single_launch.md); kept buildable for re-measurement
-#include "../../tools/scratch/ntt_single_launch_experiment.cuh"
-#endif
+#include "ntt_fused.cuh"
 #include "numth.hpp"
 #include "rns_kernels.cuh"
 #include "keygen_kernels.cuh"
@@ -183,10 +181,13 @@ struct pha_context {
     int num_cus = 0;
     int device = -1;          // the device this context was created on
     uint32_t xcd_map = 1;     // limb-to-XCD block placement of the NTT kernels (PHA_XCD_MAP=0: tile-interleaved, round 1)
-#ifdef PHA_EXPERIMENT_SINGLE_LAUNCH
-    int fused = 0, fused_wgs = 4, fused_depth = 4;
+    // single-launch pipelined transform (ntt_fused.cuh): PHA_FUSED_NTT / pha_ntt_fused_config
+    int fused = 0;                    // 0: two kernels; 1: one persistent launch where it applies
+    uint32_t fused_flags = 0;         // FUSED_* experiment switches
+    uint32_t fused_min_units = 16;    // smaller launches keep the two kernels
+    uint32_t fused_nq = 0;            // XCC ids the census found (queues)
+    uint64_t fused_xcc_queue = ~0ull; // byte x: queue of XCC id x
     DevBuf<uint32_t> fused_ctl;
-#endif
 
     NttTables fwd_tables() const {
         return NttTables{d_mod.p, d_tw.p, d_twD.p, d_n_inv.p, d_n_inv_shoup.p, static_cast<uint32_t>(log_n), twD_stride,
@@ -237,6 +238,31 @@ int ensure_workspace(pha_context *ctx, size_t words, uint64_t **out, hipStream_t
 int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(PHA_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return PHA_OK;
+}
+
+// Which XCC ids the workgroups of a grid on this device report (8 on an MI355X in SPX mode, 1 in CPX mode): the
+// single-launch transform gives every id its own task queue, so the map must be the device's, not an assumption.
+// Also allocates and zeroes the control block.  No id found (cannot happen) leaves the single launch off.
+int fused_census(pha_context *ctx) {
+    constexpr uint32_t kBlocks = 1024;
+    DevBuf<uint32_t> ids;
+    HIP_TRY(ids.alloc(kBlocks));
+    HIP_TRY(hipMemset(ids.p, 0xff, kBlocks * sizeof(uint32_t)));
+    hipLaunchKernelGGL(fused_census_kernel, dim3(kBlocks), dim3(64), 0, nullptr, ids.p);
+    PHA_TRY(check_launch("fused_census"));
+    std::vector<uint32_t> h(kBlocks);
+    HIP_TRY(hipMemcpy(h.data(), ids.p, kBlocks * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    bool seen[8] = {};
+    for (uint32_t v : h)
+        if (v < 8) seen[v] = true;
+    uint64_t map = 0;
+    uint32_t nq = 0;
+    for (int x = 0; x < 8; x++) map |= static_cast<uint64_t>(seen[x] ? nq++ : 0xffu) << (8 * x);
+    ctx->fused_nq = nq;
+    ctx->fused_xcc_queue = map;
+    HIP_TRY(ctx->fused_ctl.alloc(kFCtlWords));
+    HIP_TRY(hipMemset(ctx->fused_ctl.p, 0, kFCtlWords * sizeof(uint32_t)));
     return PHA_OK;
 }
 
@@ -408,25 +434,6 @@ void set_placement(LimbMap &lm, bool xcd, size_t polys) {
     lm.xcd_map = xcd ? 1u : 0u;
     lm.polys_magic = static_cast<uint32_t>(((1ull << 32) + polys - 1) / polys);
 }
-#ifdef PHA_EXPERIMENT_SINGLE_LAUNCH
-template <int S1, int RA1, int S2, int RA2>
-void launch_fused(bool narrow, int epi, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, const NttTables &T, const LimbMap &lm,
-                  const Epilogue &ep, const FusedArgs &fa) {
-#define PHA_FUSED_LAUNCH(E, NARROW) \
-    hipLaunchKernelGGL((fntt_fused_kernel<S1, RA1, S2, RA2, E, NARROW>), grid, dim3(kThreads), 0, st, data, ps, T, lm, ep, fa)
-    if (narrow) {
-        if (epi == EPI_SUB_MUL) PHA_FUSED_LAUNCH(EPI_SUB_MUL, true);
-        else if (epi == EPI_SUB_MUL_ADD) PHA_FUSED_LAUNCH(EPI_SUB_MUL_ADD, true);
-        else PHA_FUSED_LAUNCH(EPI_NONE, true);
-    } else {
-        if (epi == EPI_SUB_MUL) PHA_FUSED_LAUNCH(EPI_SUB_MUL, false);
-        else if (epi == EPI_SUB_MUL_ADD) PHA_FUSED_LAUNCH(EPI_SUB_MUL_ADD, false);
-        else PHA_FUSED_LAUNCH(EPI_NONE, false);
-    }
-#undef PHA_FUSED_LAUNCH
-}
-
-#endif
 
 int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stride, const NttRange &r, int epi,
                 const Epilogue &ep, hipStream_t st, int phases = 3) {
@@ -445,16 +452,24 @@ int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stri
             hipLaunchKernelGGL((small_fntt_kernel<EPI_NONE>), g, dim3(256), 0, st, data, poly_stride, T, rr.lm, ep);
         return check_launch("forward NTT (N = 2^11)");
     }
-#ifdef PHA_EXPERIMENT_SINGLE_LAUNCH
-    const size_t tiles = ctx->n >> kTileLog;
-    if (ctx->fused && phases == 3 && !T.split && ctx->plan.s1 == 8 && ctx->plan.s2 == 8 && r.active * polys <= kFusedMaxUnits) {
-        set_placement(rr.lm, false, polys);
-        const size_t tasks = 2 * static_cast<size_t>(r.active) * polys * tiles;
-        const dim3 grid(static_cast<uint32_t>(std::min<size_t>(tasks, static_cast<size_t>(ctx->num_cus) * ctx->fused_wgs)));
-        launch_fused<8, 4, 8, 4>(ctx->narrow, epi, grid, st, data, poly_stride, T, rr.lm, ep, FusedArgs{ctx->fused_ctl.p, kFusedQueues, static_cast<uint32_t>(ctx->fused_depth), static_cast<uint32_t>(ctx->fused >> 1)});
-        return check_launch("forward NTT (single launch)");
+    if (ctx->fused && phases == 3 && epi == EPI_NONE && !T.split && ctx->plan.s1 == 8 && ctx->plan.s2 == 8 && ctx->fused_nq) {
+        const size_t tiles = ctx->n >> kTileLog, units = static_cast<size_t>(r.active) * polys;
+        if (units >= ctx->fused_min_units && units <= kFusedMaxUnits) {
+            set_placement(rr.lm, false, polys);
+            const size_t tasks = 2 * units * tiles;
+            // a multiple of the queue count, so that round-robin dispatch gives every XCD the same number of workgroups
+            size_t wgs = std::min<size_t>(tasks, static_cast<size_t>(ctx->num_cus) * kFusedWgsPerCu);
+            wgs = std::max<size_t>(ctx->fused_nq, wgs / ctx->fused_nq * ctx->fused_nq);
+            const FusedArgs fa{ctx->fused_ctl.p, ctx->fused_nq, static_cast<uint32_t>(std::max<size_t>(1, wgs / ctx->fused_nq / 2)),
+                               ctx->fused_xcc_queue, ctx->fused_flags};
+            const dim3 grid(static_cast<uint32_t>(wgs));
+            if (ctx->narrow)
+                hipLaunchKernelGGL(fntt_fused_kernel<true>, grid, dim3(kThreads), 0, st, data, poly_stride, T, rr.lm, fa);
+            else
+                hipLaunchKernelGGL(fntt_fused_kernel<false>, grid, dim3(kThreads), 0, st, data, poly_stride, T, rr.lm, fa);
+            return check_launch("forward NTT (single launch)");
+        }
     }
-#endif
     const bool xcd = use_xcd_map(ctx, r.active, polys, ctx->n >> kTileLog);
     set_placement(rr.lm, xcd, polys);
     const dim3 grid(ntt_grid_blocks(xcd, r.active, polys, ctx->n >> kTileLog));
@@ -1341,13 +1356,9 @@ int pha_context_create(int log_n, const uint64_t *moduli_QP, size_t size_QP, siz
             return e && *e ? static_cast<uint32_t>(atoi(e)) : dflt;
         };
         ctx->xcd_map = env_u("PHA_XCD_MAP", 1) ? 1u : 0u;
-#ifdef PHA_EXPERIMENT_SINGLE_LAUNCH
         ctx->fused = static_cast<int>(env_u("PHA_FUSED_NTT", 0));
-        ctx->fused_wgs = std::max(1, std::min(8, static_cast<int>(env_u("PHA_FUSED_WGS", 4))));
-        ctx->fused_depth = std::max(1, static_cast<int>(env_u("PHA_FUSED_DEPTH", 4)));
-        HIP_TRY(ctx->fused_ctl.alloc(kCtlWords));
-        HIP_TRY(hipMemset(ctx->fused_ctl.p, 0, kCtlWords * sizeof(uint32_t)));
-#endif
+        ctx->fused_flags = env_u("PHA_FUSED_FLAGS", 0);
+        ctx->fused_min_units = env_u("PHA_FUSED_MIN_UNITS", 16);
         int dev = 0;
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDevice(&dev));
@@ -1360,6 +1371,7 @@ int pha_context_create(int log_n, const uint64_t *moduli_QP, size_t size_QP, siz
             g_scratch_ptr[dev] = p;
         }
     }
+    PHA_TRY(fused_census(ctx.get()));
     ctx->narrow = true;
     for (size_t i = 0; i < size_QP; i++) ctx->narrow = ctx->narrow && (moduli_QP[i] >> 60) == 0;
     ctx->host_tables.resize(size_QP);
@@ -1524,29 +1536,21 @@ int pha_ntt_launch_phase(pha_context *ctx, uint64_t *inout, size_t polys, size_t
     return ntt_forward(ctx, inout, polys, poly_stride_limbs * ctx->n, r, EPI_NONE, Epilogue{}, as_stream(stream), mask);
 }
 
-#ifdef PHA_EXPERIMENT_SINGLE_LAUNCH
-int pha_ntt_single_launch_depth(pha_context *ctx, int depth) {
+int pha_ntt_fused_config(pha_context *ctx, int enable, uint32_t flags, uint32_t min_units) {
     REQUIRE_CTX(true);
-    if (depth < 1) return fail(PHA_ERR_INVALID_ARGUMENT, "depth must be at least 1");
-    ctx->fused_depth = depth;
+    ctx->fused = enable ? 1 : 0;
+    ctx->fused_flags = flags;
+    ctx->fused_min_units = min_units;
     return PHA_OK;
 }
 
-int pha_ntt_single_launch(pha_context *ctx, int enable, int wgs_per_cu) {
-    REQUIRE_CTX(true);
-    if (wgs_per_cu < 1 || wgs_per_cu > 8) return fail(PHA_ERR_INVALID_ARGUMENT, "workgroups per CU must be 1..8");
-    ctx->fused = enable;      // bit 0: on; higher bits: FusedArgs::debug (timing experiments)
-    ctx->fused_wgs = wgs_per_cu;
-    return PHA_OK;
-}
-
-int pha_ntt_single_launch_status(pha_context *ctx, uint32_t *timed_out) {
-    REQUIRE_CTX(timed_out);
+int pha_ntt_fused_status(pha_context *ctx, uint32_t *error_word, uint32_t *queues) {
+    REQUIRE_CTX(error_word);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(timed_out, ctx->fused_ctl.p + kCtlError, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(error_word, ctx->fused_ctl.p + kFCtlError, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (queues) *queues = ctx->fused_nq;
     return PHA_OK;
 }
-#endif
 
 int pha_ntt_block_placement(pha_context *ctx, int limb_to_xcd) {
     REQUIRE_CTX(true);
