@@ -262,6 +262,8 @@ struct FpField {
 #pragma clang fp contract(off)
         return __builtin_fma(-__builtin_rint(x * qinv), q, x);
     }
+    // a * b mod q as a representative of absolute value <= q/2 + 1, for |a|, |b| <= q: a twiddle derived from generators
+    __device__ __forceinline__ elem mulred(elem a, elem b) const { return reduce(mulmod(a, prep(b))); }
     // any |v| <= 2^52 -> [0,q)
     __device__ __forceinline__ elem canon(elem v) const {
         const double r = reduce(v);

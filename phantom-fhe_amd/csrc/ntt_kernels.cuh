@@ -14,7 +14,10 @@
 // to the reference after the final reduction to [0,q).
 #pragma once
 
+#include <type_traits>
+
 #include "modarith.cuh"
+#include "numth.hpp"
 
 namespace pha {
 
@@ -78,7 +81,10 @@ struct NttTables {
                            // twiddle (8-byte records in the same order, first half of the region)
     uint32_t split;        // N = 2^17: 1 = the outermost radix-2 stage runs in its own kernel (split_*_kernel) and
                            // the column kernels transform the two halves as subtrees rooted at twiddle nodes 2, 3
+    const double *twG;     // [size_QP][kGenWords] generators of the last pass's twiddles (FP64 limbs, last pass of four
+                           // stages); nullptr: every last-pass twiddle is read from twD
 };
+constexpr uint32_t kGenWords = 304;   // = kGenStride; offsets kGenOmega, kGenAlpha, kGenBeta: numth.hpp (build_generator_table)
 
 // out[l][e] = (sub[l][e] - x) * cst[l] (+ addend[l][e])   or   x * cst[l]
 struct Epilogue {
@@ -243,6 +249,33 @@ struct LastPassTw {
     const TW *base;  // already offset to (chunk, lane)
     __device__ __forceinline__ TW operator()(int s, int jb) const { return base[((1 << s) - 1 + jb) * 64]; }
 };
+
+// The same 15 twiddles derived instead of loaded (FP64 limbs): stage s, sub-block jb uses theta^(2^(3-s)) * omega[s][jb],
+// theta = alpha[tile] * beta[lane's group] (NttTables::twG).  One 8-byte load per lane and tile replaces fifteen (a third of
+// a row pass's traffic); the price is 15 modular products per 32 butterflies.  Any representative of the residue class
+// with |w| <= q serves the butterflies, and every stored result is canonical, so results do not change.
+struct GenTw {
+    const FpField &f;
+    const double *omega;      // 16 doubles in LDS
+    double pw[4];             // theta^8, theta^4, theta^2, theta
+    __device__ __forceinline__ GenTw(const FpField &f_, const double *omega_, double theta) : f(f_), omega(omega_) {
+        pw[3] = theta;
+        pw[2] = f.mulred(theta, theta);
+        pw[1] = f.mulred(pw[2], pw[2]);
+        pw[0] = f.mulred(pw[1], pw[1]);
+    }
+    __device__ __forceinline__ double operator()(int s, int jb) const {
+        return jb == 0 ? pw[s] : f.mulred(pw[s], omega[(1 << s) - 1 + jb]);
+    }
+};
+// generator operands of a row tile: omega goes to LDS (lanes 0..15), the lane keeps theta
+template <class F>
+__device__ __forceinline__ double gen_theta(const F &, const double *, double *, uint32_t, uint32_t) { return 0.0; }
+template <>
+__device__ __forceinline__ double gen_theta<FpField>(const FpField &f, const double *twg, double *lds_omega, uint32_t ti, uint32_t t) {
+    if (t < 16) lds_omega[t] = twg[kGenOmega + t];
+    return f.mulred(twg[kGenAlpha + ti], twg[kGenBeta + t]);
+}
 
 // radix-2^R decimation-in-time block: stage s uses twiddle node*2^s + jb on sub-block jb.
 // G0 = index of the block's first stage within its kernel; the field policies (modarith.cuh)
@@ -442,11 +475,14 @@ template <int S2, int RA, int EPI, class F>
 __device__ __forceinline__ void fntt_row_body(uint64_t *lds, const uint64_t (&raw)[16], const tw_t *tw_raw,
                                               const tw_t *twd_raw, uint32_t n1, uint32_t ti, const F &f, uint64_t q,
                                               uint64_t *out, const uint64_t *sub, const uint64_t *addend, uint64_t cst,
-                                              uint64_t cst_shoup) {
+                                              uint64_t cst_shoup, const double *twg = nullptr, double *lds_omega = nullptr) {
     constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
+    constexpr bool kCanGen = std::is_same<F, FpField>::value && RB == 4 && kTileLog == 12;
     using TW = typename F::twl;
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
     const uint32_t t = pha_tid();
+    double theta = 0.0;
+    if (kCanGen && twg) theta = gen_theta(f, twg, lds_omega, ti, t);      // omega reaches LDS before the first barrier
 #pragma unroll
     for (int g = 0; g < GC; g++) {
         const uint32_t gid = t + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;
@@ -465,9 +501,19 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, const uint64_t (&ra
         typename F::elem x[1 << RB];
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(lds[lds_row(e0 + j)]);
-        const TW *twd = reinterpret_cast<const TW *>(twd_raw) +
-                        static_cast<size_t>(ggid >> 6) * (((1 << RB) - 1) * 64) + (ggid & 63);
-        ct_radix<RB, RA>(x, LastPassTw<RB, TW>{twd}, f);
+        if constexpr (kCanGen) {
+            if (twg) {
+                ct_radix<RB, RA>(x, GenTw(f, lds_omega, theta), f);
+            } else {
+                const TW *twd = reinterpret_cast<const TW *>(twd_raw) +
+                                static_cast<size_t>(ggid >> 6) * (((1 << RB) - 1) * 64) + (ggid & 63);
+                ct_radix<RB, RA>(x, LastPassTw<RB, TW>{twd}, f);
+            }
+        } else {
+            const TW *twd = reinterpret_cast<const TW *>(twd_raw) +
+                            static_cast<size_t>(ggid >> 6) * (((1 << RB) - 1) * 64) + (ggid & 63);
+            ct_radix<RB, RA>(x, LastPassTw<RB, TW>{twd}, f);
+        }
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) lds[lds_row(e0 + j)] = F::raw(f.canon_fwd(x[j]));
     }
@@ -525,12 +571,14 @@ template <int S2, int RA, int EPI, bool NARROW>
 __global__ PHA_NTT_BOUNDS void fntt_row_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm,
                                                             Epilogue ep) {
     __shared__ uint64_t lds[kLdsWords];
+    __shared__ double lds_omega[16];
     const uint32_t n = 1u << T.log_n, n1 = n >> S2, tiles = n >> kTileLog;
     BlockWork bw;
     if (!decode_block(blockIdx.x, lm, tiles, bw)) return;
     const uint32_t poly = bw.poly, ti = bw.ti;
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
+    const double *twg = T.twG ? T.twG + static_cast<size_t>(tidx) * kGenWords : nullptr;
     const size_t limb_off = static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
     uint64_t *base = data + poly * poly_stride + limb_off;
     uint64_t raw[16];
@@ -551,7 +599,8 @@ __global__ PHA_NTT_BOUNDS void fntt_row_kernel(uint64_t *data, size_t poly_strid
         cst_shoup = ep.cst_shoup[twr - ep.cst_limb0];
     }
     if (use_fp64(T, mod))
-        fntt_row_body<S2, RA, EPI>(lds, raw, tw, twd, n1, ti, FpField(mod), mod.value, out, sub, addend, cst, cst_shoup);
+        fntt_row_body<S2, RA, EPI>(lds, raw, tw, twd, n1, ti, FpField(mod), mod.value, out, sub, addend, cst, cst_shoup, twg,
+                                   lds_omega);
     else
         fntt_row_body<S2, RA, EPI>(lds, raw, tw, twd, n1, ti, IntField<NARROW>(mod), mod.value, out, sub, addend, cst,
                                    cst_shoup);
@@ -570,12 +619,16 @@ __device__ __forceinline__ void intt_row_load(uint64_t (&raw)[16], const uint64_
 }
 template <int S2, int RA, class F>
 __device__ __forceinline__ void intt_row_body(uint64_t *lds, const uint64_t (&raw)[16], uint64_t *dst, const tw_t *tw_raw,
-                                              const tw_t *twd_raw, uint32_t n1, uint32_t ti, const F &f) {
+                                              const tw_t *twd_raw, uint32_t n1, uint32_t ti, const F &f,
+                                              const double *twg = nullptr, double *lds_omega = nullptr) {
     constexpr int RB = S2 - RA, L = 1 << S2, RW = kTile >> S2, GC = 16 >> RA, GD = 16 >> RB;
+    constexpr bool kCanGen = std::is_same<F, FpField>::value && RB == 4 && kTileLog == 12;
     using TW = typename F::twl;
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
     const uint32_t t = threadIdx.x;
     const typename F::twt unused{};
+    double theta = 0.0;
+    if (kCanGen && twg) theta = gen_theta(f, twg, lds_omega, ti, t);      // omega reaches LDS before the first barrier
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint32_t e = (i * kThreads + t) * 2;
@@ -590,9 +643,19 @@ __device__ __forceinline__ void intt_row_body(uint64_t *lds, const uint64_t (&ra
         typename F::elem x[1 << RB];
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(lds[lds_row(e0 + j)]);
-        const TW *twd = reinterpret_cast<const TW *>(twd_raw) +
-                        static_cast<size_t>(ggid >> 6) * (((1 << RB) - 1) * 64) + (ggid & 63);
-        gs_radix<RB, false>(x, LastPassTw<RB, TW>{twd}, f, unused);
+        if constexpr (kCanGen) {
+            if (twg) {
+                gs_radix<RB, false>(x, GenTw(f, lds_omega, theta), f, unused);
+            } else {
+                const TW *twd = reinterpret_cast<const TW *>(twd_raw) +
+                                static_cast<size_t>(ggid >> 6) * (((1 << RB) - 1) * 64) + (ggid & 63);
+                gs_radix<RB, false>(x, LastPassTw<RB, TW>{twd}, f, unused);
+            }
+        } else {
+            const TW *twd = reinterpret_cast<const TW *>(twd_raw) +
+                            static_cast<size_t>(ggid >> 6) * (((1 << RB) - 1) * 64) + (ggid & 63);
+            gs_radix<RB, false>(x, LastPassTw<RB, TW>{twd}, f, unused);
+        }
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) lds[lds_row(e0 + j)] = F::raw(x[j]);
     }
@@ -613,12 +676,14 @@ template <int S2, int RA>
 __global__ PHA_NTT_BOUNDS void intt_row_kernel(uint64_t *out, const uint64_t *in, size_t poly_stride,
                                                             NttTables T, LimbMap lm) {
     __shared__ uint64_t lds[kLdsWords];
+    __shared__ double lds_omega[16];
     const uint32_t n = 1u << T.log_n, n1 = n >> S2, tiles = n >> kTileLog;
     BlockWork bw;
     if (!decode_block(blockIdx.x, lm, tiles, bw)) return;
     const uint32_t poly = bw.poly, ti = bw.ti;
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
+    const double *twg = T.twG ? T.twG + static_cast<size_t>(tidx) * kGenWords : nullptr;
     const size_t off = poly * poly_stride + static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
     const size_t out_off = inv_out_offset(lm, poly, poly_stride, twr, n) + static_cast<size_t>(ti) * kTile;
     uint64_t raw[16];
@@ -627,7 +692,7 @@ __global__ PHA_NTT_BOUNDS void intt_row_kernel(uint64_t *out, const uint64_t *in
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     const tw_t *twd = T.twD + static_cast<size_t>(tidx) * T.twD_stride;
     if (use_fp64(T, mod))
-        intt_row_body<S2, RA>(lds, raw, out + out_off, tw, twd, n1, ti, FpField(mod));
+        intt_row_body<S2, RA>(lds, raw, out + out_off, tw, twd, n1, ti, FpField(mod), twg, lds_omega);
     else
         intt_row_body<S2, RA>(lds, raw, out + out_off, tw, twd, n1, ti, IntField<true>(mod));
 }

@@ -128,6 +128,20 @@ bool build_limb_tables(int log_n, uint64_t q, LimbTables &t) {
     return true;
 }
 
+void build_generator_table(const LimbTables &t, int log_n, bool inverse, uint64_t *out) {
+    const size_t n = size_t(1) << log_n, groups = n >> 4, tiles = n >> 12;
+    const uint64_t q = t.q;
+    const std::vector<uint64_t> &tw = inverse ? t.itw : t.tw;      // every index used here is >= 8: itw[1]'s N^-1 is not involved
+    const uint64_t root = inverse ? inv_mod_prime(t.psi, q) : t.psi;
+    for (size_t i = 0; i < kGenStride; i++) out[i] = 0;
+    for (int s = 0; s < 4; s++)
+        for (uint32_t jb = 0; jb < (1u << s); jb++)
+            out[kGenOmega + (size_t(1) << s) - 1 + jb] = pow_mod(root, static_cast<uint64_t>(bit_reverse(jb, s)) << (log_n - s), q);
+    const uint64_t theta0_inv = inv_mod_prime(tw[groups << 3], q);
+    for (size_t ti = 0; ti < tiles; ti++) out[kGenAlpha + ti] = tw[(groups + ti * 256) << 3];
+    for (size_t l = 0; l < 256 && l < groups; l++) out[kGenBeta + l] = mul_mod(tw[(groups + l) << 3], theta0_inv, q);
+}
+
 void galois_permutation(int log_n, uint32_t galois_elt, uint32_t *table) {
     const uint32_t n = 1u << log_n;
     for (uint32_t i = 0; i < n; ++i) {

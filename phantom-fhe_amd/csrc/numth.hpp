@@ -42,6 +42,15 @@ struct LimbTables {
 // src/util/ntt.cu:11-56
 bool build_limb_tables(int log_n, uint64_t q, LimbTables &t);
 
+// Generators of the LAST register pass's twiddles (no reference counterpart: the reference reads all N twiddles of a
+// limb, src/ntt/fntt_2d.cu:148-166).  The last four stages of a transform work on groups of 16 adjacent coefficients;
+// group g (node G = n/16 + g) uses, in stage s and sub-block jb < 2^s, the table entry tw[(G << s) + jb] =
+// psi^(brev_s(jb) 2^(logn-s) + B 2^(3-s)) with B = brev_(logn-3)(G), i.e.  theta_g^(2^(3-s)) * omega[s][jb]  with
+// theta_g = tw[G << 3] and 15 per-limb constants omega; and with g = tile * 256 + t,  theta_g = alpha[tile] * beta[t].
+// Layout per limb and direction (kGenStride words): omega[16] (slot (1 << s) - 1 + jb; slot 15 unused), alpha[32], beta[256].
+constexpr size_t kGenOmega = 0, kGenAlpha = 16, kGenBeta = 48, kGenStride = 304;
+void build_generator_table(const LimbTables &t, int log_n, bool inverse, uint64_t *out);
+
 // include/galois.cuh:49-64
 void galois_permutation(int log_n, uint32_t galois_elt, uint32_t *table);
 // src/galois.cu:42-75; returns false for an out-of-range step

@@ -157,6 +157,8 @@ struct pha_context {
     std::vector<LimbTables> host_tables;
     DevBuf<DModulus> d_mod;
     DevBuf<tw_t> d_tw, d_itw, d_twD, d_itwD;
+    DevBuf<double> d_twG, d_itwG;     // generators of the last pass's twiddles (FP64 limbs; numth.hpp build_generator_table)
+    bool gen_tw = false;              // the row passes derive their last-pass twiddles (PHA_GEN_TW=0: read them from twD)
     DevBuf<uint64_t> d_n_inv, d_n_inv_shoup;
     uint32_t twD_stride = 0;
     std::map<size_t, std::unique_ptr<LevelTool>> levels;
@@ -191,11 +193,11 @@ struct pha_context {
 
     NttTables fwd_tables() const {
         return NttTables{d_mod.p, d_tw.p, d_twD.p, d_n_inv.p, d_n_inv_shoup.p, static_cast<uint32_t>(log_n), twD_stride,
-                         fp64 ? 1u : 0u, static_cast<uint32_t>(plan.split)};
+                         fp64 ? 1u : 0u, static_cast<uint32_t>(plan.split), gen_tw ? d_twG.p : nullptr};
     }
     NttTables inv_tables() const {
         return NttTables{d_mod.p, d_itw.p, d_itwD.p, d_n_inv.p, d_n_inv_shoup.p, static_cast<uint32_t>(log_n), twD_stride,
-                         fp64 ? 1u : 0u, static_cast<uint32_t>(plan.split)};
+                         fp64 ? 1u : 0u, static_cast<uint32_t>(plan.split), gen_tw ? d_itwG.p : nullptr};
     }
     bool limb_is_fp64(size_t l) const { return fp64 && (moduli[l] >> 50) == 0; }
 };
@@ -323,6 +325,24 @@ int upload_tables(pha_context *ctx) {
     HIP_TRY(ctx->d_itw.upload(itw));
     HIP_TRY(ctx->d_twD.upload(twD));
     HIP_TRY(ctx->d_itwD.upload(itwD));
+    // generators of the last-pass twiddles: only where that pass has four stages on 4096-coefficient tiles and the limb
+    // runs on FP64 (the integer butterflies need each twiddle's Shoup companion, a division per derived twiddle)
+    if (rb == 4 && kTileLog == 12 && !ctx->plan.small) {
+        static_assert(kGenWords == kGenStride, "device and host layouts of the generator table");
+        std::vector<double> g(L * kGenStride, 0.0), ig(L * kGenStride, 0.0);
+        std::vector<uint64_t> w(kGenStride);
+        for (size_t l = 0; l < L; l++) {
+            if (!ctx->limb_is_fp64(l)) continue;
+            build_generator_table(ctx->host_tables[l], ctx->log_n, false, w.data());
+            for (size_t i = 0; i < kGenStride; i++) g[l * kGenStride + i] = static_cast<double>(w[i]);
+            build_generator_table(ctx->host_tables[l], ctx->log_n, true, w.data());
+            for (size_t i = 0; i < kGenStride; i++) ig[l * kGenStride + i] = static_cast<double>(w[i]);
+        }
+        HIP_TRY(ctx->d_twG.upload(g));
+        HIP_TRY(ctx->d_itwG.upload(ig));
+        const char *e = getenv("PHA_GEN_TW");
+        ctx->gen_tw = !(e && e[0] == '0');
+    }
     HIP_TRY(ctx->d_mod.upload(mods));
     HIP_TRY(ctx->d_n_inv.upload(ninv));
     HIP_TRY(ctx->d_n_inv_shoup.upload(ninv_s));
