@@ -28,8 +28,13 @@ Extra objects on the config-2 line:
                  fabric-side byte count of one forward transform from a separate rocprofv3 --pmc pass
                  (tools/profile.sh -> profiles/traffic_latest.json), reported only when that file was produced from
                  the kernel sources this run uses (hash of csrc/), else null.
+                 `int_path` is the same forward transform on a chain of 36 sixty-bit primes (every limb on the
+                 32-bit-multiply butterflies; the headline chain has 35 of 36 limbs on the FP64 butterflies).
   cpu_baseline — the oracle (a scalar port; kind "port") timed on the host cores on a bounded sample of the same
                  workload.
+The config-3 and config-4 lines carry `roofline` (SURVEY.md §8(d)'s ~0.9 GiB of algorithmic traffic per key-switched
+operation against 8 TB/s per GPU that took part) and, at one rank, `cpu_baseline` (the oracle's key switch on the host).
+`n_gpus` counts the distinct devices the ranks ran on; `ranks` the processes.
 """
 import argparse
 import hashlib
@@ -52,6 +57,7 @@ BITS = [60] + [50] * 35  # BASELINE.md config 2 / SURVEY.md §8(d): first prime 
 SIZE_P = 12              # configs 3 / 4: 12 special primes of 60 bits (dnum 3)
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_LIMB = N * 8 * 2
+KS_ALGO_BYTES = 0.9 * 2 ** 30   # HMult + relinearise at config 3, every buffer once per producing / consuming kernel
 BUTTERFLIES_PER_LIMB = (N // 2) * LOG_N
 # measured issue peaks on MI355X (tools/ubench.hip, profiles/r1a_ubench.log), lane-operations per second chip-wide
 INT32_MUL_PEAK = 31.03e12    # v_mad_u64_u32
@@ -142,6 +148,58 @@ def max_over_ranks(elapsed, dist, device):
 
 def aggregate_value(units_per_rank_step, steps, world, elapsed):
     return world * units_per_rank_step * steps / elapsed
+
+
+def devices_used(torch, dist, world):
+    """Distinct GPUs the ranks ran on (two ranks may share one device in a rehearsal on a one-GPU box)."""
+    if dist is None or world == 1:
+        return 1
+    mine = torch.tensor([torch.cuda.current_device() if torch.cuda.is_available() else 0], dtype=torch.int64,
+                        device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    return len({int(t.item()) for t in every})
+
+
+def keyswitch_cpu_baseline(rotate, budget_s=10.0):
+    """The oracle's HMult + relinearise (or rotation) at the config-3 shapes on the host cores, bounded sample."""
+    import numpy as np
+
+    import oracle
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    oracle.build()
+    mods = oracle.coeff_modulus_create(N, [60] + [50] * (LIMBS - 1) + [60] * SIZE_P)
+    orc = oracle.Oracle(LOG_N, mods, SIZE_P)
+    ct1 = np.ascontiguousarray(orc.uniform_poly(list(range(LIMBS)) * 2, 3).reshape(2, LIMBS, N))
+    ct2 = np.ascontiguousarray(orc.uniform_poly(list(range(LIMBS)) * 2, 4).reshape(2, LIMBS, N))
+    key_idx = list(range(LIMBS)) + list(range(LIMBS, LIMBS + SIZE_P))
+    evk = [np.ascontiguousarray(orc.uniform_poly(key_idx * 2, 5 + d).reshape(2, LIMBS + SIZE_P, N)) for d in range(orc.beta(LIMBS))]
+    elt = 5
+    done, t0 = 0, time.perf_counter()
+    while True:
+        if rotate:
+            c0 = orc.apply_galois_ntt(ct1[0], elt)
+            c1 = orc.apply_galois_ntt(ct1[1], elt)
+            ct = np.ascontiguousarray(np.stack([c0, np.zeros_like(c1)]))
+            orc.keyswitch_inplace(LIMBS, ct, c1, evk)
+        else:
+            d = orc.tensor_prod_2x2(ct1, ct2)
+            ct = np.ascontiguousarray(d[:2])
+            orc.keyswitch_inplace(LIMBS, ct, np.ascontiguousarray(d[2]), evk)
+        done += 1
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            break
+    what = "rotations (apply_galois + key switch)" if rotate else "HMult + relinearise"
+    base = {"cores": threads, "kind": "port", "host_cores_visible": os.cpu_count(),
+            "sample": f"{done} {what}, N=2^16, 36 + 12 limbs, dnum 3, in {el:.1f} s, OpenMP over limbs on {threads} threads"}
+    if rotate:
+        base.update(value=done / el, unit="ciphertexts/s")
+    else:
+        base.update(value=1e3 * el / done, unit="ms")
+    return base
 
 
 def timed_steps(step, steps, warmup, dist, sync, device):
@@ -244,6 +302,16 @@ def secondary_metrics(torch, pha):
     res["config"] = "N=2^16, 36 Q limbs + 12 special primes (dnum 3), uniform synthetic ciphertexts and keys"
     ctx.close()
     del evk, ct1, ct2, dst
+    # the same operation on a chain whose 13 wide limbs (q0 and the special primes) are 50-bit too: every transform on
+    # the FP64 butterflies
+    mods = pha.coeff_modulus_create(N, [50] * (size_q + size_p))
+    ctx = pha.PhantomContext(LOG_N, mods, size_p)
+    lo = int(mods.min())
+    evk = pha.EvalKey([rnd(2, size_q + size_p) for _ in range(size_q // size_p)])
+    ct1, ct2 = rnd(3, size_q), rnd(2, size_q)
+    res["hmult_relin_all_50bit_ms"] = timed(lambda: ctx.multiply_and_relin_inplace(1, ct1, ct2, evk))
+    ctx.close()
+    del evk, ct1, ct2
 
     from phantom_fhe_amd.bootstrap import Bootstrapper
     from phantom_fhe_amd.ckks import GpuEvaluator
@@ -365,6 +433,22 @@ def roofline_config2(torch, ctx, buf, orig, mods, args):
     }
     if note:
         roof["traffic_note"] = note
+    # the same transform with every limb on the integer butterflies (the reference's grids are 55/60-bit chains,
+    # tests/relin.cu:98-130, and q0 + the special primes of configs[2] are 60-bit)
+    import phantom_fhe_amd as pha
+    imods = pha.coeff_modulus_create(N, [60] * LIMBS)
+    ictx = pha.PhantomContext(LOG_N, imods, 0)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    ibuf = torch.randint(0, int(imods.min()), (POLYS, LIMBS, N), dtype=torch.int64, device="cuda", generator=g)
+    ifwd = lambda: ictx.ntt_forward_batched(ibuf, POLYS, LIMBS, LIMBS, 0)  # noqa: E731
+    for _ in range(10):
+        ifwd()
+    torch.cuda.synchronize()
+    ims = event_time_ms(torch, ifwd, reps)
+    ictx.close()
+    roof["int_path"] = {"chain": "36 primes of 60 bits", "avg_launch_ms": ims, "achieved": algo / (ims * 1e-3) / 1e9,
+                        "frac": algo / (ims * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "frac_of_int32_mul_peak": POLYS * LIMBS * BUTTERFLIES_PER_LIMB * MUL32_PER_INT_BUTTERFLY / INT32_MUL_PEAK / (ims * 1e-3)}
     return roof
 
 
@@ -388,8 +472,8 @@ def run_config2(args, torch, pha, rank, world, dist):
     units_per_step = 2 * POLYS * LIMBS
     out = {
         "metric": "RNS-NTT limb-transforms/s @N=2^16 (forward+inverse, 36 limbs x 2 polys per GPU)",
-        "value": aggregate_value(units_per_step, args.steps, world, elapsed), "unit": "limb-transforms/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "value": aggregate_value(units_per_step, args.steps, world, elapsed), "unit": "limb-transforms/s",
+        "n_gpus": devices_used(torch, dist, world), "ranks": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "configs[1]: batched RNS NTT+INTT, N=2^16, 36 limbs x 2 polys, uint64[2][36][65536] per GPU",
                    "limbs": LIMBS, "polys": POLYS, "log_n": LOG_N, "parallelism": f"independent batches x{world}"},
@@ -431,15 +515,24 @@ def run_config3(args, torch, pha, rank, world, dist):
 
     elapsed = timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda")
     q0, qc, p0, pc = ev.windows(1)[rank]
+    ndev = devices_used(torch, dist, world)
     out = {
         "metric": "CKKS HMult + relinearise ms @N=2^16, L=35 (36 + 12 limbs, dnum 3), limbs sharded over the GPUs",
-        "value": 1e3 * elapsed / args.steps, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": 1e3 * elapsed / args.steps, "unit": "ms", "n_gpus": ndev, "ranks": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": "configs[2]: HMult + relinearise (hybrid key switch, dnum 3), N=2^16, 36 Q + 12 P limbs",
                    "parallelism": f"limb-parallel x{world}: equal limb blocks, 1 + 2 in-place all-gathers per key switch",
                    "rank0_window": {"q_begin": q0, "q_count": qc, "p_begin": p0, "p_count": pc}},
     }
+    if rank == 0:
+        # ~0.9 GiB of algorithmic traffic per HMult + relinearise, against 8 TB/s on every GPU that took part
+        ach = KS_ALGO_BYTES / (elapsed / args.steps) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "HMult + relinearise, whole operation (all ranks)", "achieved": ach,
+                           "peak": HBM_PEAK_GBS * ndev, "unit": "GB/s", "frac": ach / (HBM_PEAK_GBS * ndev), "traffic": None,
+                           "algorithmic_bytes_per_launch": KS_ALGO_BYTES}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = keyswitch_cpu_baseline(rotate=False)
     ctx.close()
     return out
 
@@ -465,12 +558,23 @@ def run_config4(args, torch, pha, rank, world, dist):
     elapsed = timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda")
     out = {
         "metric": "CKKS rotate (apply_galois + key switch) ciphertexts/s, 64 independent ciphertexts @N=2^16, 36 + 12 limbs",
-        "value": total * args.steps / elapsed, "unit": "ciphertexts/s", "n_gpus": world, "steps": args.steps,
+        "value": total * args.steps / elapsed, "unit": "ciphertexts/s", "n_gpus": devices_used(torch, dist, world), "ranks": world,
+        "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "configs[3]: rotate by one slot, 64 independent ciphertexts, N=2^16, 36 Q + 12 P limbs (dnum 3)",
                    "parallelism": f"ciphertexts dealt to {world} ranks ({hi_u - lo_u} on rank 0), batches of {batch} per launch sequence"},
     }
+    if rank == 0:
+        # a rotation = key switch + two gathers: SURVEY.md §8(d)'s 0.9 GiB minus the tensor product's 126 MiB plus 72 MiB
+        algo = KS_ALGO_BYTES - 126 * 2 ** 20 + 72 * 2 ** 20
+        ach = algo * out["value"] / 1e9
+        ndev = out["n_gpus"]
+        out["roofline"] = {"bound": "hbm", "kernel": "rotate = Galois gather + key switch, whole operation (all ranks)", "achieved": ach,
+                           "peak": HBM_PEAK_GBS * ndev, "unit": "GB/s", "frac": ach / (HBM_PEAK_GBS * ndev), "traffic": None,
+                           "algorithmic_bytes_per_launch": algo}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = keyswitch_cpu_baseline(rotate=True)
     ctx.close()
     return out
 
@@ -480,7 +584,7 @@ def run_dry(args, rank, world, dist):
     elapsed = timed_steps(lambda: None, args.steps, args.warmup, dist, lambda: None, "cpu")
     lo, hi = shard_units(64, world, rank)
     return {"metric": "dry run (no GPU work)", "value": aggregate_value(1, args.steps, world, max(elapsed, 1e-9)), "unit": "steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+            "n_gpus": world, "ranks": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "none", "rank0_units_of_64": hi - lo}}
 

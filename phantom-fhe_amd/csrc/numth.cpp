@@ -231,6 +231,61 @@ static void mw_mul_word(std::vector<uint64_t> &a, uint64_t w) {  // a *= w, a ha
     }
 }
 
+void build_bconv_mfma_table(const uint64_t *matrix, const uint64_t *moduli, size_t ibase, size_t obase, BconvMfmaTable &out) {
+    out = BconvMfmaTable{};
+    if (ibase == 0 || ibase > 15 || obase == 0) return;
+    for (size_t j = 0; j < obase; j++)
+        if (moduli[j] <= (1ull << 32) || (moduli[j] >> 61) != 0) return;
+    typedef unsigned __int128 u128;
+    const uint32_t ksteps = ibase <= 7 ? 1 : 2;
+    const size_t quads = (obase + 3) / 4, quad_bytes = 2 * ksteps * 1024;
+    out.ksteps = ksteps;
+    out.quads = static_cast<uint32_t>(quads);
+    out.table.assign(quads * quad_bytes, 0);
+    out.consts.assign(quads * 4 * 2, 0);
+    auto digits = [](uint64_t x, int8_t d[8]) {   // balanced base-256 digits of x < 2^62
+        for (int s = 0; s < 8; s++) {
+            int64_t v = static_cast<int64_t>(x & 255);
+            if (v >= 128) v -= 256;
+            d[s] = static_cast<int8_t>(v);
+            x = (x - static_cast<uint64_t>(v)) >> 8;   // exact: x - v is a multiple of 256 (wraps only when x < |v|, x small)
+        }
+    };
+    for (size_t j = 0; j < quads * 4; j++) {
+        const size_t quad = j / 4, g = j % 4;
+        if (j >= obase) {   // padding rows: a harmless modulus, all-zero digits
+            out.consts[j * 2] = (1ull << 33) + 1;
+            out.consts[j * 2 + 1] = static_cast<uint64_t>((static_cast<u128>(1) << 96) / out.consts[j * 2]);
+            continue;
+        }
+        const uint64_t p = moduli[j];
+        out.consts[j * 2] = p;
+        out.consts[j * 2 + 1] = static_cast<uint64_t>((static_cast<u128>(1) << 96) / p);
+        u128 sum = 0;                 // sum over (i, a) of (2^(8a) M[j][i]) mod p
+        auto put = [&](size_t slot_i, size_t a, uint64_t value) {
+            int8_t d[8];
+            digits(value, d);
+            const size_t kstep = slot_i / 8, gk = (slot_i % 8) / 2, jb = (slot_i % 2) * 8 + a;
+            for (int s = 0; s < 8; s++) {
+                const size_t t = s / 4, r = s % 4, lane = 16 * gk + 4 * g + r;
+                out.table[quad * quad_bytes + ((t * ksteps + kstep) * 64 + lane) * 16 + jb] = static_cast<uint8_t>(d[s]);
+            }
+        };
+        for (size_t i = 0; i < ibase; i++) {
+            const uint64_t m = matrix[j * ibase + i] % p;
+            for (size_t a = 0; a < 8; a++) {
+                const uint64_t v = static_cast<uint64_t>((static_cast<u128>(m) << (8 * a)) % p);
+                sum += v;
+                put(i, a, v);
+            }
+        }
+        // the constant slot: input index ibase, byte 0, against a data byte 1
+        const u128 bias = static_cast<u128>(kBmfBiasLimb) + (static_cast<u128>(kBmfBiasLimb) << 32);
+        const uint64_t c = static_cast<uint64_t>((sum * 128 % p + p - bias % p) % p);
+        put(ibase, 0, c);
+    }
+}
+
 void build_crt_tables(const uint64_t *moduli, size_t l, CrtTables &t) {
     t.l = l;
     t.big_q.assign(l, 0);

@@ -74,6 +74,27 @@ struct LevelConstants {
 };
 void build_level_constants(const std::vector<uint64_t> &moduli_QP, size_t size_P, size_t size_Ql, LevelConstants &lc);
 
+// Base conversion on the matrix cores (rns_kernels.cuh: bconv_mfma_kernel; no reference counterpart, the reference's
+// bconv_matmul_*_kernel, src/rns_bconv.cu:143-168, multiplies 64-bit words on the vector ALU).  The product
+//   out_j = sum_i y_i M[j][i]  mod p_j
+// is rewritten over the bytes of the inputs: y_i = sum_a u_ia 2^(8a), t_ia = u_ia - 128 (a signed byte), and
+//   out_j = sum_s 2^(8s) sum_(i,a) t_ia w[j][i][a][s] + C_j   (mod p_j),   s = 0..7,
+// where w[j][i][a][.] are the eight BALANCED base-256 digits (in [-128, 127]) of (2^(8a) M[j][i]) mod p_j and C_j =
+// 128 sum_(i,a) (2^(8a) M[j][i] mod p_j).  The inner sums are one i8 matrix product with K = 8 ibase + 1: the extra
+// slot multiplies a constant byte 1 by the digits of (C_j - kBmfBias) mod p_j, kBmfBias being what the kernel adds to
+// keep its accumulator non-negative.  Table layout, per QUAD of four outputs (j = 4 quad + g): [tile t = 0, 1][k-step]
+// [lane = 16 g' + 4 g + r][16 bytes]: the A operand of v_mfma_i32_16x16x64_i8 whose row 4 g + r is digit s = 4 t + r
+// of output j; byte jb of lane group g' is slot (input i = 8 kstep + 2 g' + jb / 8, byte a = jb % 8).
+// consts: [quads * 4][2] = {p_j, floor(2^96 / p_j)}.  ksteps = 0 (no table): ibase > 15 or a modulus <= 2^32.
+constexpr uint64_t kBmfBiasLimb = 1ull << 46;     // added to each of the two 32-bit-spaced halves of the accumulator
+struct BconvMfmaTable {
+    uint32_t ksteps = 0, quads = 0;
+    std::vector<uint8_t> table;       // [quads][2][ksteps][64][16]
+    std::vector<uint64_t> consts;     // [quads * 4][2]
+};
+// matrix [obase][ibase] (row j reduced mod moduli[j]); moduli [obase]
+void build_bconv_mfma_table(const uint64_t *matrix, const uint64_t *moduli, size_t ibase, size_t obase, BconvMfmaTable &out);
+
 // CRT composition tables of the base q_0..q_{l-1} (src/util/rns.cu RNSBase::initialize, used by
 // compose_array src/rns_base.cu:236-402): multi-word little-endian integers of l words
 struct CrtTables {

@@ -38,6 +38,7 @@ namespace {
 
 constexpr int kMaxDevices = 64;
 uint64_t *g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mutex;   // guards the fill of g_scratch_ptr (pha_context_create)
 
 thread_local std::string g_last_error;
 
@@ -122,6 +123,33 @@ struct ShoupVec {
     }
 };
 
+// device copy of a BconvMfmaTable (numth.hpp); `digits` tables of equal shape back to back for the batched modup
+struct BconvMfmaDev {
+    DevBuf<uint8_t> table;
+    DevBuf<uint64_t> consts;
+    uint32_t ksteps = 0, quads = 0;
+    size_t table_stride = 0, consts_stride = 0;   // bytes / words from one digit's table to the next
+    hipError_t upload(const std::vector<BconvMfmaTable> &digits) {
+        ksteps = 0;
+        if (digits.empty() || !digits[0].ksteps) return hipSuccess;
+        std::vector<uint8_t> t;
+        std::vector<uint64_t> c;
+        for (const auto &dg : digits) {
+            if (dg.ksteps != digits[0].ksteps || dg.quads != digits[0].quads) return hipSuccess;   // no table: vector-ALU kernel
+            t.insert(t.end(), dg.table.begin(), dg.table.end());
+            c.insert(c.end(), dg.consts.begin(), dg.consts.end());
+        }
+        hipError_t e = table.upload(t);
+        if (e == hipSuccess) e = consts.upload(c);
+        if (e != hipSuccess) return e;
+        ksteps = digits[0].ksteps;
+        quads = digits[0].quads;
+        table_stride = digits[0].table.size();
+        consts_stride = digits[0].consts.size();
+        return hipSuccess;
+    }
+};
+
 // DRNSTool for one data level (src/rns.cu:11-192, CKKS subset)
 struct LevelTool {
     size_t size_Ql = 0, beta = 0;
@@ -131,6 +159,8 @@ struct LevelTool {
     std::vector<DevBuf<uint32_t>> modup_obase_tidx;      // per digit: table index of each output limb
     DevBuf<uint64_t> moddown_matrix;
     DevBuf<uint32_t> moddown_obase_tidx;
+    std::vector<BconvMfmaDev> modup_mfma;                // per digit: the same matrices as matrix-core operands
+    BconvMfmaDev moddown_mfma, modup_mfma_all;
     // merged relinearise + rescale: division by B = {q_{l-1}} u P in one moddown (built on first use)
     struct MergedDown {
         bool ready = false;
@@ -167,6 +197,8 @@ struct pha_context {
     hipStream_t ws_stream = nullptr;   // the stream of the last call that took the workspace (ensure_workspace)
     bool ws_used = false;
     hipEvent_t ws_event = nullptr;
+    bool ws_event_valid = false;       // ws_event was recorded after the last workspace-using call
+    bool ws_shared = false;            // more than one stream has used this context: calls record ws_event as they return
     DevBuf<uint64_t> d_bigP_mod_q;  // key level, [size_Q] (key generation)
     // helper stream for the independent giant-step chains of pha_linear_transform_double_hoisted
     static constexpr int kAuxStreams = 3;                // helper streams of the double-hoisted transform's giant chains
@@ -182,6 +214,7 @@ struct pha_context {
 
     int num_cus = 0;
     int device = -1;          // the device this context was created on
+    bool bconv_mfma = true;   // base conversions on the matrix cores where a table exists (PHA_BCONV_MFMA=0: vector ALU)
     uint32_t xcd_map = 1;     // limb-to-XCD block placement of the NTT kernels (PHA_XCD_MAP=0: tile-interleaved, round 1)
     // single-launch pipelined transform (ntt_fused.cuh): PHA_FUSED_NTT / pha_ntt_fused_config
     int fused = 0;                    // 0: two kernels; 1: one persistent launch where it applies
@@ -204,11 +237,15 @@ struct pha_context {
 
 namespace {
 
-// The context's one workspace, for a call on stream `st`.  Calls on one stream are ordered by the stream; when a call
-// arrives on another stream than the last one, the new stream first waits for everything enqueued on the old one (an
-// event recorded there now), so two streams sharing a context are serialised instead of racing on t_mod_up / cx /
-// scratch.  Concurrent work needs one context per stream (ckks.py: GpuEvaluator.sibling).  Growing the buffer
-// synchronises the device and allocates: not possible while `st` is capturing -- run the call once before the capture.
+// The context's one workspace, for a call on stream `st`.  Calls on one stream are ordered by the stream.  The first time
+// a call arrives on another stream than the one before it the device is synchronised once and the context is marked as
+// shared between streams; from then on every call that took the workspace records ws_event on its own stream when it
+// returns (WsLease below), and a call on a different stream waits for that event before it touches t_mod_up / cx /
+// scratch.  The old stream's handle is never used again, so the caller may destroy it.  Concurrent work needs one context
+// per stream (ckks.py: GpuEvaluator.sibling).  Captured work is outside this tracking: a capturing stream cannot wait for
+// eager work and a graph replay is invisible here, so replays of a context must not overlap other work on that context
+// (INTEGRATION.md).  Growing the buffer synchronises the device and allocates: not possible while `st` is capturing --
+// run the call once before the capture.
 int ensure_workspace(pha_context *ctx, size_t words, uint64_t **out, hipStream_t st) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     HIP_TRY(hipStreamIsCapturing(st, &cap));
@@ -219,23 +256,38 @@ int ensure_workspace(pha_context *ctx, size_t words, uint64_t **out, hipStream_t
         // the old buffer may still be in use by enqueued kernels
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(ctx->workspace.alloc(words));
-    } else if (ctx->ws_used && ctx->ws_stream != st) {
-        hipStreamCaptureStatus prev = hipStreamCaptureStatusNone;
-        const bool alive = hipStreamIsCapturing(ctx->ws_stream, &prev) == hipSuccess;   // the caller may have destroyed it
-        if (!alive) (void)hipGetLastError();
-        // a capturing stream may only wait for work of its own capture; what ran before the capture began was
-        // synchronised by whoever began it
-        if (alive && (cap == hipStreamCaptureStatusNone) == (prev == hipStreamCaptureStatusNone)) {
-            if (!ctx->ws_event) HIP_TRY(hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming));
-            HIP_TRY(hipEventRecord(ctx->ws_event, ctx->ws_stream));
+        ctx->ws_event_valid = false;   // everything recorded so far has completed
+    } else if (ctx->ws_used && ctx->ws_stream != st && cap == hipStreamCaptureStatusNone) {
+        if (ctx->ws_event_valid) {
             HIP_TRY(hipStreamWaitEvent(st, ctx->ws_event, 0));
+        } else if (!ctx->ws_shared) {
+            HIP_TRY(hipDeviceSynchronize());   // once per context: the calls so far recorded nothing
         }
+        ctx->ws_shared = true;
     }
     ctx->ws_stream = st;
     ctx->ws_used = true;
     *out = ctx->workspace.p;
     return PHA_OK;
 }
+
+// Marks the end of a call's use of the workspace: on a context that more than one stream has used, records ws_event
+// on the call's stream so that the next call on another stream can wait for it.
+struct WsLease {
+    pha_context *ctx;
+    hipStream_t st;
+    WsLease(pha_context *c, hipStream_t s) : ctx(c), st(s) {}
+    WsLease(const WsLease &) = delete;
+    WsLease &operator=(const WsLease &) = delete;
+    ~WsLease() {
+        if (!ctx->ws_shared) return;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        ctx->ws_event_valid = false;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
+        if (!ctx->ws_event && hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming) != hipSuccess) return;
+        ctx->ws_event_valid = hipEventRecord(ctx->ws_event, st) == hipSuccess;
+    }
+};
 
 int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
@@ -563,6 +615,8 @@ int get_level(pha_context *ctx, size_t chain_index, LevelTool **out) {
     HIP_TRY(lt->PHatInv.upload(lt->host.PHatInv_mod_p, P));
     lt->modup_matrix.resize(lt->beta);
     lt->modup_obase_tidx.resize(lt->beta);
+    lt->modup_mfma.resize(lt->beta);
+    std::vector<BconvMfmaTable> digit_tables(lt->beta);
     for (size_t d = 0; d < lt->beta; d++) {
         const size_t s = d * ctx->size_P, e = std::min(s + ctx->size_P, size_Ql);
         std::vector<uint32_t> tidx;
@@ -572,6 +626,13 @@ int get_level(pha_context *ctx, size_t chain_index, LevelTool **out) {
         }
         HIP_TRY(lt->modup_matrix[d].upload(lt->host.modup_matrix[d]));
         HIP_TRY(lt->modup_obase_tidx[d].upload(tidx));
+        if (ctx->size_P > 1) {
+            std::vector<uint64_t> omod(tidx.size());
+            for (size_t j = 0; j < tidx.size(); j++) omod[j] = ctx->moduli[tidx[j]];
+            digit_tables[d] = BconvMfmaTable{};
+            build_bconv_mfma_table(lt->host.modup_matrix[d].data(), omod.data(), e - s, omod.size(), digit_tables[d]);
+            HIP_TRY(lt->modup_mfma[d].upload({digit_tables[d]}));
+        }
     }
     lt->uniform_digits = ctx->size_P > 1 && size_Ql % ctx->size_P == 0;
     if (lt->uniform_digits) {
@@ -587,20 +648,51 @@ int get_level(pha_context *ctx, size_t chain_index, LevelTool **out) {
         }
         HIP_TRY(lt->modup_matrix_all.upload(mall));
         HIP_TRY(lt->modup_tidx_all.upload(tall));
+        HIP_TRY(lt->modup_mfma_all.upload(digit_tables));
     }
     std::vector<uint32_t> tidx(size_Ql);
     for (size_t j = 0; j < size_Ql; j++) tidx[j] = static_cast<uint32_t>(j);
     HIP_TRY(lt->moddown_matrix.upload(lt->host.moddown_matrix));
     HIP_TRY(lt->moddown_obase_tidx.upload(tidx));
+    if (ctx->size_P > 1) {
+        BconvMfmaTable t;
+        build_bconv_mfma_table(lt->host.moddown_matrix.data(), ctx->moduli.data(), ctx->size_P, size_Ql, t);
+        HIP_TRY(lt->moddown_mfma.upload({t}));
+    }
     *out = lt.get();
     ctx->levels[size_Ql] = std::move(lt);
     return PHA_OK;
 }
 
+// mf: the matrix as matrix-core operands (nullptr or empty: none).  That path needs 16-byte aligned buffers and N >= 256.
 int launch_bconv(pha_context *ctx, uint64_t *dst, const uint64_t *y, const uint64_t *matrix, const uint32_t *obase_tidx,
                  uint32_t ibase, uint32_t obase, uint32_t skip_start, uint32_t skip_len, uint32_t batch,
-                 const BconvBatch &bt, hipStream_t st) {
+                 const BconvBatch &bt, hipStream_t st, const BconvMfmaDev *mf = nullptr) {
     const uint32_t n = static_cast<uint32_t>(ctx->n);
+    const bool use_mfma = ctx->bconv_mfma;
+    auto aligned16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (use_mfma && mf && mf->ksteps && n >= 256 && mf->quads == (obase + 3) / 4 && aligned16(dst) && aligned16(y) &&
+        aligned16(bt.copy_src)) {
+        // every group of quads re-reads the inputs and stages its operands in LDS (at most 60 KiB of it)
+        static const uint32_t target_wgs = [] {
+            const char *e = getenv("PHA_BCONV_MFMA_WGS");
+            return e ? static_cast<uint32_t>(atoi(e)) : 2048u;
+        }();
+        const uint32_t quad_bytes = 2 * mf->ksteps * 1024 + 64, max_qpb = (60u << 10) / quad_bytes;
+        const uint32_t base = (n / 256) * batch;
+        uint32_t groups = std::min<uint32_t>(mf->quads, std::max<uint32_t>(1, (target_wgs + base - 1) / base));
+        uint32_t qpb = std::min<uint32_t>((mf->quads + groups - 1) / groups, max_qpb);
+        groups = (mf->quads + qpb - 1) / qpb;
+        const dim3 g(n / 256, groups, batch);
+        const size_t lds = static_cast<size_t>(qpb) * quad_bytes;
+        // z runs over digits (each with its own matrix) only when the vector-ALU kernel's matrix advances with it
+        const size_t tstride = bt.matrix_stride ? mf->table_stride : 0, cstride = bt.matrix_stride ? mf->consts_stride : 0;
+        if (mf->ksteps == 1)
+            hipLaunchKernelGGL((bconv_mfma_kernel<1>), g, dim3(256), lds, st, dst, y, mf->table.p, mf->consts.p, tstride, cstride, ibase, obase, qpb, n, skip_start, skip_len, bt);
+        else
+            hipLaunchKernelGGL((bconv_mfma_kernel<2>), g, dim3(256), lds, st, dst, y, mf->table.p, mf->consts.p, tstride, cstride, ibase, obase, qpb, n, skip_start, skip_len, bt);
+        return check_launch("bconv_mfma");
+    }
     // Every output-limb group re-reads the ibase input limbs: as few groups as still give ~4096 workgroups
     // (measured at configs[2]: targets 512..9216 give HMult 0.343 / 0.331 / 0.332 / 0.327 / 0.336 ms; a batch of 16
     // rotations needs one group and gains 2.5 %); PHA_BCONV_WGS overrides the target for experiments.
@@ -653,7 +745,7 @@ int do_modup(pha_context *ctx, LevelTool *lt, uint64_t *dst, const uint64_t *cks
                           static_cast<uint32_t>(alpha), cks, alpha * n, 0, 0, 0};
             PHA_TRY(launch_bconv(ctx, dst, t_cks, lt->modup_matrix_all.p, lt->modup_tidx_all.p,
                                  static_cast<uint32_t>(alpha), obase, 0, static_cast<uint32_t>(alpha),
-                                 static_cast<uint32_t>(lt->beta), bt, st));
+                                 static_cast<uint32_t>(lt->beta), bt, st, &lt->modup_mfma_all));
         } else {
             for (size_t d = 0; d < lt->beta; d++) {
                 const size_t s = d * alpha, e = std::min(s + alpha, size_Ql), len = e - s;
@@ -661,7 +753,7 @@ int do_modup(pha_context *ctx, LevelTool *lt, uint64_t *dst, const uint64_t *cks
                 PHA_TRY(launch_bconv(ctx, dst + d * size_QlP * n, t_cks + s * n, lt->modup_matrix[d].p,
                                      lt->modup_obase_tidx[d].p, static_cast<uint32_t>(len),
                                      static_cast<uint32_t>(size_QlP - len), static_cast<uint32_t>(s),
-                                     static_cast<uint32_t>(len), 1, bt, st));
+                                     static_cast<uint32_t>(len), 1, bt, st, &lt->modup_mfma[d]));
             }
         }
     }
@@ -704,7 +796,8 @@ int do_modup_batched(pha_context *ctx, LevelTool *lt, uint64_t *dst, const uint6
                   static_cast<uint32_t>(lt->beta), in_stride, in_stride};
     PHA_TRY(launch_bconv(ctx, dst, t_cks, single ? lt->modup_matrix[0].p : lt->modup_matrix_all.p,
                          single ? lt->modup_obase_tidx[0].p : lt->modup_tidx_all.p, static_cast<uint32_t>(len), obase, 0,
-                         static_cast<uint32_t>(len), static_cast<uint32_t>(lt->beta * batch), bt, st));
+                         static_cast<uint32_t>(len), static_cast<uint32_t>(lt->beta * batch), bt, st,
+                         single ? &lt->modup_mfma[0] : &lt->modup_mfma_all));
     NttRange rr;
     PHA_TRY(make_range(ctx, size_QlP, 0, ctx->size_QP, alpha, 0, 0, rr));
     rr.lm.digit_alpha = static_cast<uint32_t>(alpha);
@@ -752,7 +845,7 @@ int do_moddown(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *cx, uint
         BconvBatch bt{size_Ql * n, size_QlP * n, 0, 0, 0, nullptr, 0, 0, 0, 0};
         PHA_TRY(launch_bconv(ctx, delta, cp, lt->moddown_matrix.p, lt->moddown_obase_tidx.p, static_cast<uint32_t>(alpha),
                              static_cast<uint32_t>(size_Ql), static_cast<uint32_t>(size_Ql), 0,
-                             static_cast<uint32_t>(polys), bt, st));
+                             static_cast<uint32_t>(polys), bt, st, &lt->moddown_mfma));
     }
     NttRange rq;
     PHA_TRY(make_range(ctx, size_Ql, 0, 0, 0, 0, 0, rq));
@@ -857,6 +950,7 @@ int do_keyswitch(pha_context *ctx, LevelTool *lt, uint64_t *ct, const uint64_t *
     const size_t n = ctx->n, size_Ql = lt->size_Ql, size_QlP = size_Ql + ctx->size_P;
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n, &ws, st));
+    WsLease ws_lease(ctx, st);
     uint64_t *t_mod_up = ws, *cx = t_mod_up + lt->beta * size_QlP * n, *scratch = cx + 2 * size_QlP * n;
     PHA_TRY(do_modup(ctx, lt, t_mod_up, c2, scratch, st));
     PHA_TRY(do_inner_prod(ctx, lt, cx, t_mod_up, evks, st));
@@ -959,7 +1053,7 @@ int lp_modup_finish(pha_context *ctx, LevelTool *lt, uint64_t *t_mod_up, const u
                           static_cast<uint32_t>(alpha), c2_ntt, alpha * n, 0, 0, 0};
             PHA_TRY(launch_bconv(ctx, t_mod_up, c2_coeff, lt->modup_matrix_all.p, lt->modup_tidx_all.p,
                                  static_cast<uint32_t>(alpha), obase, 0, static_cast<uint32_t>(alpha),
-                                 static_cast<uint32_t>(lt->beta), owned(bt), st));
+                                 static_cast<uint32_t>(lt->beta), owned(bt), st, &lt->modup_mfma_all));
         } else {
             for (size_t d = 0; d < lt->beta; d++) {
                 const size_t s = d * alpha, e = std::min(s + alpha, size_Ql), len = e - s;
@@ -967,7 +1061,7 @@ int lp_modup_finish(pha_context *ctx, LevelTool *lt, uint64_t *t_mod_up, const u
                 PHA_TRY(launch_bconv(ctx, t_mod_up + d * size_QlP * n, c2_coeff + s * n, lt->modup_matrix[d].p,
                                      lt->modup_obase_tidx[d].p, static_cast<uint32_t>(len),
                                      static_cast<uint32_t>(size_QlP - len), static_cast<uint32_t>(s),
-                                     static_cast<uint32_t>(len), 1, owned(bt), st));
+                                     static_cast<uint32_t>(len), 1, owned(bt), st, &lt->modup_mfma[d]));
             }
         }
     }
@@ -1047,6 +1141,7 @@ int lp_moddown_finish(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *c
     const size_t n = ctx->n, size_Ql = lt->size_Ql, alpha = ctx->size_P, size_QlP = size_Ql + alpha;
     uint64_t *delta;
     PHA_TRY(ensure_workspace(ctx, 2 * size_Ql * n, &delta, st));
+    WsLease ws_lease(ctx, st);
     if (alpha == 1) {
         hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(static_cast<uint32_t>(n / 512), 2u), dim3(256), 0, st, delta,
                            p_coeff + (p_rows ? p_rows[0] : 0) * n, ctx->d_mod.p, static_cast<uint32_t>(w.q0),
@@ -1059,9 +1154,13 @@ int lp_moddown_finish(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *c
             bt.in_rows_set = 1;
             for (size_t k = 0; k < alpha; k++) bt.in_row[k] = p_rows[k];
         }
-        PHA_TRY(launch_bconv(ctx, delta + w.q0 * n, p_coeff, lt->moddown_matrix.p + w.q0 * alpha, lt->moddown_obase_tidx.p + w.q0,
-                             static_cast<uint32_t>(alpha), static_cast<uint32_t>(w.qc), static_cast<uint32_t>(w.qc), 0, 2,
-                             bt, st));
+        // the whole matrix with this rank's Q window as the owned outputs
+        bt.own_set = 1;
+        bt.own[0] = static_cast<uint32_t>(w.q0);
+        bt.own[1] = static_cast<uint32_t>(w.q0 + w.qc);
+        bt.own[2] = bt.own[3] = 0;
+        PHA_TRY(launch_bconv(ctx, delta, p_coeff, lt->moddown_matrix.p, lt->moddown_obase_tidx.p, static_cast<uint32_t>(alpha),
+                             static_cast<uint32_t>(size_Ql), static_cast<uint32_t>(size_Ql), 0, 2, bt, st, &lt->moddown_mfma));
     }
     NttRange rq;
     PHA_TRY(make_range(ctx, w.qc, w.q0, 0, 0, 0, 0, rq));
@@ -1376,6 +1475,7 @@ int pha_context_create(int log_n, const uint64_t *moduli_QP, size_t size_QP, siz
             return e && *e ? static_cast<uint32_t>(atoi(e)) : dflt;
         };
         ctx->xcd_map = env_u("PHA_XCD_MAP", 1) ? 1u : 0u;
+        ctx->bconv_mfma = env_u("PHA_BCONV_MFMA", 1) != 0;
         ctx->fused = static_cast<int>(env_u("PHA_FUSED_NTT", 0));
         ctx->fused_flags = env_u("PHA_FUSED_FLAGS", 0);
         ctx->fused_min_units = env_u("PHA_FUSED_MIN_UNITS", 16);
@@ -1384,11 +1484,15 @@ int pha_context_create(int log_n, const uint64_t *moduli_QP, size_t size_QP, siz
         HIP_TRY(hipGetDevice(&dev));
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
         ctx->device = dev;
-        if (dev >= 0 && dev < kMaxDevices && !g_scratch_ptr[dev]) {
-            // this device's copy of the scratch array (every GPU holds its own, at its own address)
-            uint64_t *p = nullptr;
-            HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void **>(&p), HIP_SYMBOL(scratch)));
-            g_scratch_ptr[dev] = p;
+        if (dev >= 0 && dev < kMaxDevices) {
+            // this device's copy of the scratch array (every GPU holds its own, at its own address); contexts may be
+            // created from several threads at once
+            std::lock_guard<std::mutex> lock(g_scratch_mutex);
+            if (!g_scratch_ptr[dev]) {
+                uint64_t *p = nullptr;
+                HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void **>(&p), HIP_SYMBOL(scratch)));
+                g_scratch_ptr[dev] = p;
+            }
         }
     }
     PHA_TRY(fused_census(ctx.get()));
@@ -1584,6 +1688,7 @@ int pha_modup(pha_context *ctx, size_t chain_index, uint64_t *dst, const uint64_
     PHA_TRY(get_level(ctx, chain_index, &lt));
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, lt->size_Ql * ctx->n, &ws, as_stream(stream)));
+    WsLease ws_lease(ctx, as_stream(stream));
     return do_modup(ctx, lt, dst, cks, ws, as_stream(stream));
 }
 
@@ -1602,6 +1707,7 @@ int pha_moddown_from_ntt(pha_context *ctx, size_t chain_index, uint64_t *ct_i, u
     PHA_TRY(get_level(ctx, chain_index, &lt));
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, lt->size_Ql * ctx->n, &ws, as_stream(stream)));
+    WsLease ws_lease(ctx, as_stream(stream));
     return do_moddown(ctx, lt, ct_i, cx_i, ws, nullptr, 1, as_stream(stream));
 }
 
@@ -1645,6 +1751,7 @@ int pha_apply_galois_ntt(pha_context *ctx, const uint64_t *operand, size_t coeff
     if (result == operand) {
         uint64_t *ws;
         PHA_TRY(ensure_workspace(ctx, coeff_mod_size * ctx->n, &ws, st));
+        WsLease ws_lease(ctx, st);
         PHA_TRY(do_galois(ctx, operand, coeff_mod_size, perm, ws, st));
         HIP_TRY(hipMemcpyAsync(result, ws, coeff_mod_size * ctx->n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
         return PHA_OK;
@@ -1725,6 +1832,7 @@ int pha_apply_galois_inplace(pha_context *ctx, size_t chain_index, uint64_t *ct,
     const size_t ks_words = (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n;
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, ks_words + 2 * size_Ql * n, &ws, st));
+    WsLease ws_lease(ctx, st);
     uint64_t *temp = ws + ks_words;
     // c0 <- galois(c0); temp1 <- galois(c1); c1 <- 0; ct += KS(temp1)   (src/evaluate.cu:774-793): the moddown
     // epilogue writes ct = (galois(c0), 0) + KS directly — no copy of galois(c0), no memset of c1
@@ -1740,6 +1848,7 @@ int pha_rescale_to_next(pha_context *ctx, size_t chain_index, const uint64_t *sr
     if (lt->size_Ql < 2) return fail(PHA_ERR_INVALID_ARGUMENT, "end of modulus switching chain reached");
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, cipher_size * ctx->n, &ws, as_stream(stream)));
+    WsLease ws_lease(ctx, as_stream(stream));
     return rescale_with_scratch(ctx, lt, src, cipher_size, dst, ws, as_stream(stream));
 }
 
@@ -1920,6 +2029,7 @@ int pha_encrypt_zero_asymmetric(pha_context *ctx, const uint64_t *pk, size_t cha
     // workspace: u[QP] | cx[2][QP] | delta[2][Q] | top[2][Q]
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, (3 * QP + 4 * Q) * n, &ws, st));
+    WsLease ws_lease(ctx, st);
     uint64_t *u = ws, *cx = u + QP * n, *delta = cx + 2 * QP * n, *top = delta + 2 * Q * n;
     NttRange r;
     PHA_TRY(make_range(ctx, QP, 0, 0, 0, 0, 0, r));
@@ -1961,6 +2071,7 @@ int pha_ckks_decrypt(pha_context *ctx, const uint64_t *sk, const uint64_t *ct, s
     if (cipher_size > 2) {
         uint64_t *sp;
         PHA_TRY(ensure_workspace(ctx, limbs * n, &sp, st));
+        WsLease ws_lease(ctx, st);
         const uint64_t *prev = sk;
         for (size_t i = 2; i < cipher_size; i++) {
             PHA_TRY(launch_ew(ctx, EW_MUL, sp, prev, sk, nullptr, nullptr, 0, limbs, st));
@@ -1981,6 +2092,7 @@ int pha_gen_relinkey(pha_context *ctx, const uint64_t *sk, uint64_t seed, uint64
     REQUIRE_CTX(sk && evks_host);
     uint64_t *s2;
     PHA_TRY(ensure_workspace(ctx, ctx->size_Q * ctx->n, &s2, as_stream(stream)));
+    WsLease ws_lease(ctx, as_stream(stream));
     PHA_TRY(launch_ew(ctx, EW_MUL, s2, sk, sk, nullptr, nullptr, 0, ctx->size_Q, as_stream(stream)));
     return do_kswitch_key(ctx, sk, s2, seed, evks_host, as_stream(stream));
 }
@@ -1992,6 +2104,7 @@ int pha_gen_galois_key(pha_context *ctx, const uint64_t *sk, uint32_t galois_elt
     PHA_TRY(get_galois_table(ctx, galois_elt, &perm));
     uint64_t *sg;
     PHA_TRY(ensure_workspace(ctx, ctx->size_Q * ctx->n, &sg, as_stream(stream)));
+    WsLease ws_lease(ctx, as_stream(stream));
     PHA_TRY(do_galois(ctx, sk, ctx->size_Q, perm, sg, as_stream(stream)));
     return do_kswitch_key(ctx, sk, sg, seed, evks_host, as_stream(stream));
 }
@@ -2075,6 +2188,7 @@ int do_ckks_encode(pha_context *ctx, const double *values_host, size_t values_si
     while ((1u << log_s) < S) log_s++;
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, 4 * s + 2, &ws, st));
+    WsLease ws_lease(ctx, st);
     double2 *buf = reinterpret_cast<double2 *>(ws), *tmp = buf + s;
     unsigned long long *d_max = reinterpret_cast<unsigned long long *>(tmp + s);
     HIP_TRY(hipMemsetAsync(buf, 0, s * sizeof(double2), st));
@@ -2138,6 +2252,7 @@ int pha_ckks_decode(pha_context *ctx, const uint64_t *plain, size_t chain_index,
     while ((1u << log_s) < S) log_s++;
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, limbs * n + 4 * sparse_slots, &ws, st));
+    WsLease ws_lease(ctx, st);
     uint64_t *copy = ws;
     double2 *buf = reinterpret_cast<double2 *>(ws + limbs * n), *tmp = buf + sparse_slots;
     NttRange r;
@@ -2166,6 +2281,7 @@ int pha_rotate_hoisted(pha_context *ctx, size_t chain_index, const uint64_t *ct,
     hipStream_t st = as_stream(stream);
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n, &ws, st));
+    WsLease ws_lease(ctx, st);
     uint64_t *t_mod_up = ws, *cx = t_mod_up + lt->beta * size_QlP * n, *scratch = cx + 2 * size_QlP * n;
     PHA_TRY(do_modup(ctx, lt, t_mod_up, ct + size_Ql * n, scratch, st));  // once for every rotation
     for (size_t r = 0; r < n_rot; r++) {
@@ -2229,6 +2345,7 @@ int pha_linear_transform_double_hoisted(pha_context *ctx, size_t chain_index, co
     const size_t chain_words = ((lt->beta + 6) * size_QlP + 4 * size_Ql) * n;   // t_mod_up | cx | acc | total | scratch | u
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, n_chains * chain_words + 2 * n_baby * size_QlP * n, &ws, st));
+    WsLease ws_lease(ctx, st);
     struct Chain {
         hipStream_t st;
         uint64_t *t_mod_up, *cx, *acc, *total, *scratch, *u;
@@ -2336,6 +2453,7 @@ int pha_apply_galois_batched(pha_context *ctx, size_t chain_index, const uint64_
             PHA_TRY(do_galois(ctx, in + b * ct_words, 2 * size_Ql, perm, out + b * ct_words, st));
             uint64_t *ws;
             PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 3 * size_Ql) * n, &ws, st));
+            WsLease ws_lease(ctx, st);
             uint64_t *c2 = ws + (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n;
             HIP_TRY(hipMemcpyAsync(c2, out + b * ct_words + size_Ql * n, size_Ql * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
             HIP_TRY(hipMemsetAsync(out + b * ct_words + size_Ql * n, 0, size_Ql * n * sizeof(uint64_t), st));
@@ -2346,6 +2464,7 @@ int pha_apply_galois_batched(pha_context *ctx, size_t chain_index, const uint64_
     // workspace: t_mod_up [batch][beta][QlP] | cx [batch][2][QlP] | t_cks [batch][2][Ql] (poly 1 slots used) | delta [2 batch][Ql]
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, batch * (lt->beta * size_QlP + 2 * size_QlP + 4 * size_Ql) * n, &ws, st));
+    WsLease ws_lease(ctx, st);
     uint64_t *t_mod_up = ws, *cx = t_mod_up + batch * lt->beta * size_QlP * n, *t_cks = cx + batch * 2 * size_QlP * n,
              *delta = t_cks + batch * ct_words;
     // permute both polys of every ciphertext (src/evaluate.cu:747-794)
@@ -2377,6 +2496,7 @@ int pha_multiply_relin_rescale(pha_context *ctx, size_t chain_index, const uint6
     }
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 5 * size_Ql) * n, &ws, st));
+    WsLease ws_lease(ctx, st);
     uint64_t *t_mod_up = ws, *cx = t_mod_up + lt->beta * size_QlP * n, *scratch = cx + 2 * size_QlP * n, *d = scratch + 2 * size_Ql * n;
     {   // tensor product, doubled here when asked: before the division the doubling is exact
         const dim3 tg(static_cast<uint32_t>(size_Ql) * (static_cast<uint32_t>(n) / 512));
@@ -2427,6 +2547,7 @@ int pha_multiply_relin_rescale_batched(pha_context *ctx, size_t chain_index, siz
     const size_t d_words = 3 * size_Ql * n;
     uint64_t *ws;
     PHA_TRY(ensure_workspace(ctx, batch * (lt->beta * size_QlP + 2 * size_QlP + 2 * 3 * size_Ql + 2 * size_Ql) * n, &ws, st));
+    WsLease ws_lease(ctx, st);
     uint64_t *t_mod_up = ws, *cx = t_mod_up + batch * lt->beta * size_QlP * n, *d = cx + batch * 2 * size_QlP * n,
              *t_cks = d + batch * d_words, *delta = t_cks + batch * d_words;
     const uint32_t n32 = static_cast<uint32_t>(n), ql = static_cast<uint32_t>(size_Ql), qlp = static_cast<uint32_t>(size_QlP);
@@ -2456,6 +2577,7 @@ int pha_mod_raise(pha_context *ctx, const uint64_t *src, uint64_t *dst, pha_stre
     const size_t n = ctx->n, limbs = ctx->size_Q;
     uint64_t *coeff;
     PHA_TRY(ensure_workspace(ctx, 2 * n, &coeff, st));
+    WsLease ws_lease(ctx, st);
     // limb 0 of both polys to coefficient form (the lowest level has one limb: polys are n apart)
     NttRange r0;
     PHA_TRY(make_range(ctx, 1, 0, 0, 0, 0, 0, r0));

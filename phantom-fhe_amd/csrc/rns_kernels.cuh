@@ -5,6 +5,7 @@
 #pragma once
 
 #include "modarith.cuh"
+#include "numth.hpp"
 
 namespace pha {
 
@@ -110,6 +111,134 @@ __global__ __launch_bounds__(256) void bconv_matmul_kernel(uint64_t *__restrict_
         const u128_t acc = dot_residues<IB>(in, matrix + static_cast<size_t>(j) * IB);
         const DModulus m = obase_mod[obase_tidx[j]];
         dst[static_cast<size_t>(jo) * n + k] = barrett128(acc, m);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same conversion on the matrix cores (numth.hpp: build_bconv_mfma_table states the arithmetic and the table
+// layout).  It is a real matrix product -- [obase x 8 ibase] digits times [8 ibase x N] input bytes -- and on the
+// vector ALU it is bound by instruction issue (profiles/r2c_bconv.md: 176 instructions per output and wave), so the
+// byte products go to v_mfma_i32_16x16x64_i8 and the vector ALU is left with recombining eight 21-bit partial sums
+// and one 80 -> 61-bit Barrett step per output.
+// A workgroup converts 256 coefficients (64 per wave, as two pairs of 16-coefficient MFMA column groups: lane (g, c)
+// loads 16 bytes = coefficients 2c, 2c + 1 of inputs 2g, 2g + 1 per k-step, which ARE its B operands after an xor)
+// for the quads of blockIdx.y, whose A operands and constants it stages in LDS once.  Lane (g, c) ends up with all
+// eight partial sums of output 4 quad + g at its coefficient: no cross-lane step, 16-byte stores.
+// ---------------------------------------------------------------------------------------------
+typedef int bm_v4i __attribute__((ext_vector_type(4)));
+constexpr uint32_t kBmOperandBytes = 1024;   // one A operand: 64 lanes x 16 bytes
+
+__device__ __forceinline__ uint64_t bm_finish(const bm_v4i &d0, const bm_v4i &d1, uint64_t p, uint64_t mu) {
+    // |partial sum| < 2^21: the 32-bit halves cannot overflow, v0, v1 land in [0, 2^47)
+    const int32_t lo0 = d0.x + d0.y * 256, hi0 = d0.z + d0.w * 256;
+    const int32_t lo1 = d1.x + d1.y * 256, hi1 = d1.z + d1.w * 256;
+    const uint64_t v0 = static_cast<uint64_t>(static_cast<int64_t>(lo0) + static_cast<int64_t>(hi0) * 65536 +
+                                              static_cast<int64_t>(kBmfBiasLimb));
+    const uint64_t v1 = static_cast<uint64_t>(static_cast<int64_t>(lo1) + static_cast<int64_t>(hi1) * 65536 +
+                                              static_cast<int64_t>(kBmfBiasLimb));
+    // x = v0 + 2^32 v1 < 2^80; xh = floor(x / 2^32); qhat = floor(xh mu / 2^64) in [floor(x / p) - 2, floor(x / p)]
+    const uint64_t xh = v1 + (v0 >> 32);
+    const uint64_t xlo = (xh << 32) | lo32(v0);
+    const uint64_t qhat = mulhi64(xh, mu);
+    uint64_t r = xlo - qhat * p;    // < 3p < 2^63
+    r = csub(r, p << 1);
+    return csub(r, p);
+}
+
+template <int KSTEPS>
+__global__ __launch_bounds__(256) void bconv_mfma_kernel(uint64_t *__restrict__ dst, const uint64_t *__restrict__ y,
+                                                         const uint8_t *__restrict__ table, const uint64_t *__restrict__ consts,
+                                                         size_t table_stride, size_t consts_stride, uint32_t ibase,
+                                                         uint32_t obase, uint32_t quads_per_block, uint32_t n,
+                                                         uint32_t skip_start, uint32_t skip_len, BconvBatch bt) {
+    extern __shared__ __align__(16) uint8_t bm_lds[];
+    constexpr uint32_t kQuadBytes = 2 * KSTEPS * kBmOperandBytes;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const uint32_t z = blockIdx.z, d = bt.group ? z % bt.group : z, b = bt.group ? z / bt.group : 0;
+    dst += z * bt.dst_stride;
+    y += d * bt.y_stride + b * bt.y_group_stride;
+    table += d * table_stride;
+    consts += d * consts_stride;
+    skip_start += d * bt.skip_stride;
+    const uint64_t *src = bt.copy_src ? bt.copy_src + d * bt.copy_stride + b * bt.copy_group_stride : nullptr;
+    const uint32_t quads = (obase + 3) >> 2, q0 = blockIdx.y * quads_per_block, nq = min(quads_per_block, quads - q0);
+    const bool copies = src != nullptr && blockIdx.y == 0;
+    if (bt.own_set) {   // a workgroup none of whose outputs (or copies) this rank owns has nothing to do
+        bool any = copies && skip_start < bt.own[1] && skip_start + ibase > bt.own[0];
+        for (uint32_t j = q0 * 4; j < min((q0 + nq) * 4, obase) && !any; j++) any = bconv_owned(bt, j + (j >= skip_start ? skip_len : 0));
+        if (!any) return;
+    }
+    // A operands and constants of this workgroup's quads
+    {
+        const uint4 *tsrc = reinterpret_cast<const uint4 *>(table + static_cast<size_t>(q0) * kQuadBytes);
+        uint4 *tdst = reinterpret_cast<uint4 *>(bm_lds);
+        for (uint32_t i = tid; i < nq * (kQuadBytes / 16); i += 256) tdst[i] = tsrc[i];
+        const uint4 *csrc = reinterpret_cast<const uint4 *>(consts) + q0 * 4;
+        uint4 *cdst = reinterpret_cast<uint4 *>(bm_lds + static_cast<size_t>(quads_per_block) * kQuadBytes);
+        for (uint32_t i = tid; i < nq * 4; i += 256) cdst[i] = csrc[i];
+    }
+    // the inputs: ld[kstep][pair][h] = coefficients k0 + 32 pair + {0, 1} of input 8 kstep + 2 g + h, bytes biased by -128
+    const uint32_t k0 = blockIdx.x * 256 + wave * 64 + 2 * c;
+    bm_v4i ld[KSTEPS][2][2];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t i = ks * 8 + 2 * g + h;
+            const uint32_t row = bt.in_rows_set ? bt.in_row[min(i, 15u)] : i;
+#pragma unroll
+            for (int pr = 0; pr < 2; pr++) {
+                bm_v4i v = {0, 0, 0, 0};
+                if (i < ibase) {
+                    v = *reinterpret_cast<const bm_v4i *>(y + static_cast<size_t>(row) * n + k0 + 32 * pr);
+                    v ^= static_cast<int>(0x80808080u);
+                } else if (i == ibase) {
+                    v.x = 1;   // the constant slot (both coefficients of the pair: words 0 and 2)
+                    v.z = 1;
+                }
+                ld[ks][pr][h] = v;
+            }
+        }
+    if (copies) {   // the digit's own limbs, already in NTT form (src/rns_bconv.cu:522-528)
+        for (uint32_t i = tid >> 7; i < ibase; i += 2)
+            if (bconv_owned(bt, skip_start + i)) {
+                const size_t off = static_cast<size_t>(blockIdx.x) * 256 + (tid & 127) * 2;
+                *reinterpret_cast<uint4 *>(dst + static_cast<size_t>(skip_start + i) * n + off) =
+                    *reinterpret_cast<const uint4 *>(src + static_cast<size_t>(i) * n + off);
+            }
+    }
+    __syncthreads();
+    const uint4 *lds_c = reinterpret_cast<const uint4 *>(bm_lds + static_cast<size_t>(quads_per_block) * kQuadBytes);
+    for (uint32_t q = 0; q < nq; q++) {
+        bm_v4i a[2][KSTEPS];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ks++)
+                a[t][ks] = reinterpret_cast<const bm_v4i *>(bm_lds + (q * 2 * KSTEPS + t * KSTEPS + ks) * kBmOperandBytes)[lane];
+        const uint4 cst = lds_c[q * 4 + g];
+        const uint64_t p = pack64(cst.x, cst.y), mu = pack64(cst.z, cst.w);
+        const uint32_t j = (q0 + q) * 4 + g, jo = j + (j >= skip_start ? skip_len : 0);
+        const bool store = j < obase && bconv_owned(bt, jo);
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++) {
+            uint64_t out[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                bm_v4i d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ks++) {
+                    const bm_v4i bop = {ld[ks][pr][0][2 * e], ld[ks][pr][0][2 * e + 1], ld[ks][pr][1][2 * e], ld[ks][pr][1][2 * e + 1]};
+                    d0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0][ks], bop, d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1][ks], bop, d1, 0, 0, 0);
+                }
+                out[e] = bm_finish(d0, d1, p, mu);
+            }
+            if (store) {
+                const uint4 o = {lo32(out[0]), hi32(out[0]), lo32(out[1]), hi32(out[1])};
+                *reinterpret_cast<uint4 *>(dst + static_cast<size_t>(jo) * n + k0 + 32 * pr) = o;
+            }
+        }
     }
 }
 

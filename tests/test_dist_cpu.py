@@ -62,7 +62,7 @@ def test_bench_gpus_flag_launches_ranks():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["config"]["rank0_units_of_64"] == 32
+    assert res["n_gpus"] == 2 and res["ranks"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["config"]["rank0_units_of_64"] == 32
     # one rank: no child process, same line shape
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0",
                           "--dry-run"], capture_output=True, text=True, timeout=120, env=env)

@@ -153,7 +153,8 @@ def test_torch_distributed_ranks(gpu, backend, nproc):
 @pytest.mark.parametrize("config,steps", [(2, 20), (3, 5), (4, 2)])
 def test_bench_legs_with_two_ranks(gpu, config, steps):
     """bench.py --gpus 2: the script starts its two ranks itself (torch.distributed.run child), both share this GPU and
-    rendezvous over gloo (RCCL refuses two ranks on one device); every leg prints one line with n_gpus = 2."""
+    rendezvous over gloo (RCCL refuses two ranks on one device); every leg prints one line with ranks = 2 and n_gpus = the
+    number of distinct devices the ranks ran on (1 on a one-GPU box)."""
     import json
     import os
     import subprocess
@@ -164,5 +165,9 @@ def test_bench_legs_with_two_ranks(gpu, config, steps):
                           "--steps", str(steps), "--warmup", "1"], capture_output=True, text=True, timeout=170, env=env)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["steps"] == steps and line["value"] > 0
+    import torch
+    assert line["ranks"] == 2 and line["n_gpus"] == min(2, torch.cuda.device_count())
+    assert line["steps"] == steps and line["value"] > 0
+    if config != 2:
+        assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["peak"] == 8000.0 * line["n_gpus"]
     assert line["scaling"] == ("weak" if config == 2 else "strong")
