@@ -522,7 +522,7 @@ def run_config3(args, torch, pha, rank, world, dist):
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": "configs[2]: HMult + relinearise (hybrid key switch, dnum 3), N=2^16, 36 Q + 12 P limbs",
-                   "parallelism": f"limb-parallel x{world}: equal limb blocks, 1 + 2 in-place all-gathers per key switch",
+                   "parallelism": f"limb-parallel x{world}: balanced limb windows over Q_l u P, 2 in-place all-gathers per key switch",
                    "rank0_window": {"q_begin": q0, "q_count": qc, "p_begin": p0, "p_count": pc}},
     }
     if rank == 0:

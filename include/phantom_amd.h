@@ -219,29 +219,34 @@ int pha_prepare_level(pha_context *ctx, size_t chain_index);
  *                -> all-gather the P limbs of cx (both polys)
  *   moddown_finish: ct[owned] += key-switched part
  * Results on the owned limbs are bit-identical to pha_keyswitch_inplace / pha_rescale_to_next. */
-/* c2_coeff[l] = INTT(c2_ntt[l]) * partQlHatInv_l for the owned Q limbs (src/rns_bconv.cu:530-560) */
-int pha_lp_modup_begin(pha_context *ctx, size_t chain_index, const uint64_t *c2_ntt, uint64_t *c2_coeff,
-                       size_t q_begin, size_t q_count, pha_stream_t stream);
-/* owned limbs of every digit of t_mod_up from the gathered c2_coeff (src/rns_bconv.cu:560-628) */
+/* Exchange buffers: rank r owns rows [r * block, (r + 1) * block) of a buffer of world * block rows of N words (block =
+ * the largest window of any rank), so that ONE in-place all-gather fills it whatever each rank owns; the calls below
+ * take the buffer's row count (for validation), the first row of this rank's block and, on the reading side, a host
+ * table "limb -> row" (NULL: limb j at row j).
+ * c2_coeff row (row_begin + j) = INTT(c2_ntt[q_begin + j]) * partQlHatInv for the owned Q limbs (src/rns_bconv.cu:530-560) */
+int pha_lp_modup_begin(pha_context *ctx, size_t chain_index, const uint64_t *c2_ntt, uint64_t *c2_coeff, size_t c2_coeff_rows,
+                       size_t row_begin, size_t q_begin, size_t q_count, pha_stream_t stream);
+/* owned limbs of every digit of t_mod_up from the gathered c2_coeff (src/rns_bconv.cu:560-628); q_rows_host[j] = row of
+ * limb j in c2_coeff (size_Ql entries, at most 64 limbs; NULL: row j) */
 int pha_lp_modup_finish(pha_context *ctx, size_t chain_index, uint64_t *t_mod_up, const uint64_t *c2_ntt,
-                        const uint64_t *c2_coeff_gathered, size_t q_begin, size_t q_count, size_t p_begin,
-                        size_t p_count, pha_stream_t stream);
+                        const uint64_t *c2_coeff_gathered, size_t c2_coeff_rows, const uint32_t *q_rows_host, size_t q_begin,
+                        size_t q_count, size_t p_begin, size_t p_count, pha_stream_t stream);
 /* owned limbs of cx (src/eval_key_switch.cu:12-88); rlk as in pha_key_switch_inner_prod */
 int pha_lp_key_switch_inner_prod(pha_context *ctx, size_t chain_index, uint64_t *p_cx, const uint64_t *p_t_mod_up,
                                  const uint64_t *const *rlk, size_t q_begin, size_t q_count, size_t p_begin,
                                  size_t p_count, pha_stream_t stream);
-/* owned P limbs of both polys of cx: INTT and * PHatInv (src/rns_bconv.cu:776-800), written to
- * p_coeff[2][p_coeff_poly_stride_limbs][N], owned limb p_begin + j at row row_begin + j -- the buffer the ranks
- * all-gather in place (rank r's block of rows is block r of the buffer, whatever limbs it owns) */
-int pha_lp_moddown_begin(pha_context *ctx, size_t chain_index, const uint64_t *cx, uint64_t *p_coeff,
+/* owned P limbs of both polys of cx: INTT and * PHatInv (src/rns_bconv.cu:776-800); owned limb p_begin + j of poly p
+ * goes to row (p * p_coeff_poly_stride_limbs + row_begin + j) of p_coeff.  With p_coeff_poly_stride_limbs = block and
+ * row_begin = 2 * block * rank both polys of a rank sit in ONE contiguous block: one all-gather for the moddown. */
+int pha_lp_moddown_begin(pha_context *ctx, size_t chain_index, const uint64_t *cx, uint64_t *p_coeff, size_t p_coeff_rows,
                          size_t p_coeff_poly_stride_limbs, size_t row_begin, size_t p_begin, size_t p_count,
                          pha_stream_t stream);
 /* ct[owned] += (cx - NTT(bconv(gathered p_coeff))) * P^-1 (src/rns_bconv.cu:800-828,
- * src/eval_key_switch.cu:157-177); p_rows_host[k] = row of special limb k in p_coeff (host array of alpha entries;
- * NULL: row k) */
+ * src/eval_key_switch.cu:157-177); special limb k of poly p is row (p * p_coeff_poly_stride_limbs + p_rows_host[k]) of
+ * p_coeff (host array of alpha entries, at most 64; NULL: row k) */
 int pha_lp_moddown_finish(pha_context *ctx, size_t chain_index, uint64_t *ct, uint64_t *cx, const uint64_t *p_coeff_gathered,
-                          size_t p_coeff_poly_stride_limbs, const uint32_t *p_rows_host, size_t q_begin, size_t q_count,
-                          pha_stream_t stream);
+                          size_t p_coeff_rows, size_t p_coeff_poly_stride_limbs, const uint32_t *p_rows_host, size_t q_begin,
+                          size_t q_count, pha_stream_t stream);
 /* tensor_prod_2x2 / tensor_square_2x2 (src/polymath.cu:468-537) on the owned limbs [q_begin, q_begin + q_count) of
  * operands [2][coeff_modulus_size][N]; result [3][coeff_modulus_size][N]; operand1 == operand2 squares */
 int pha_lp_tensor_prod_2x2(pha_context *ctx, const uint64_t *operand1, const uint64_t *operand2, size_t coeff_modulus_size,

@@ -109,11 +109,11 @@ SIGNATURES = {
                                                    ctypes.POINTER(_vp), _vp, _vp]),
     "pha_mod_raise": (_int, [_vp, _vp, _vp, _vp]),
     "pha_gen_secretkey_sparse": (_int, [_vp, _u64, _sz, _vp, _vp]),
-    "pha_lp_modup_begin": (_int, [_vp, _sz, _vp, _vp, _sz, _sz, _vp]),
-    "pha_lp_modup_finish": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "pha_lp_modup_begin": (_int, [_vp, _sz, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "pha_lp_modup_finish": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32), _sz, _sz, _sz, _sz, _vp]),
     "pha_lp_key_switch_inner_prod": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
-    "pha_lp_moddown_begin": (_int, [_vp, _sz, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
-    "pha_lp_moddown_finish": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32), _sz, _sz, _vp]),
+    "pha_lp_moddown_begin": (_int, [_vp, _sz, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
+    "pha_lp_moddown_finish": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _sz, ctypes.POINTER(ctypes.c_uint32), _sz, _sz, _vp]),
     "pha_lp_tensor_prod_2x2": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     "pha_lp_rescale_begin": (_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
     "pha_lp_rescale_finish": (_int, [_vp, _sz, _vp, _vp, _sz, _vp, _sz, _sz, _vp]),
@@ -577,27 +577,34 @@ class PhantomContext:
 
     # limb-parallel steps (include/phantom_amd.h "limb-parallel key switch"); w = (q_begin, q_count,
     # p_begin, p_count), orchestrated by limb_parallel.LimbParallelEvaluator ------------------
-    def lp_modup_begin(self, chain_index, c2_ntt, c2_coeff, w):
-        _check(lib().pha_lp_modup_begin(self._h, chain_index, _ptr(c2_ntt), _ptr(c2_coeff), w[0], w[1], _stream()))
+    def lp_modup_begin(self, chain_index, c2_ntt, c2_coeff, w, row_begin=None):
+        """c2_coeff [rows][N]: owned limb w[0] + j lands on row row_begin + j (default: its own index)"""
+        _check(lib().pha_lp_modup_begin(self._h, chain_index, _ptr(c2_ntt), _ptr(c2_coeff), c2_coeff.shape[0],
+                                        w[0] if row_begin is None else row_begin, w[0], w[1], _stream()))
 
-    def lp_modup_finish(self, chain_index, t_mod_up, c2_ntt, c2_coeff, w):
-        _check(lib().pha_lp_modup_finish(self._h, chain_index, _ptr(t_mod_up), _ptr(c2_ntt), _ptr(c2_coeff), w[0], w[1],
-                                         w[2], w[3], _stream()))
+    def lp_modup_finish(self, chain_index, t_mod_up, c2_ntt, c2_coeff, w, q_rows=None):
+        """q_rows[j] = row of limb j in the gathered c2_coeff (default: j)"""
+        rows = None if q_rows is None else (ctypes.c_uint32 * len(q_rows))(*q_rows)
+        _check(lib().pha_lp_modup_finish(self._h, chain_index, _ptr(t_mod_up), _ptr(c2_ntt), _ptr(c2_coeff), c2_coeff.shape[0],
+                                         rows, w[0], w[1], w[2], w[3], _stream()))
 
     def lp_key_switch_inner_prod(self, chain_index, cx, t_mod_up, evk, w):
         _check(lib().pha_lp_key_switch_inner_prod(self._h, chain_index, _ptr(cx), _ptr(t_mod_up), evk.ptr, w[0], w[1],
                                                   w[2], w[3], _stream()))
 
-    def lp_moddown_begin(self, chain_index, cx, p_coeff, w, row_begin=None):
-        """p_coeff [2][rows][N]: owned P limb w[2] + j of poly z lands on p_coeff[z, row_begin + j] (default: its own index)"""
-        _check(lib().pha_lp_moddown_begin(self._h, chain_index, _ptr(cx), _ptr(p_coeff), p_coeff.shape[1],
+    def lp_moddown_begin(self, chain_index, cx, p_coeff, w, row_begin=None, poly_stride=None):
+        """Owned P limb w[2] + j of poly z lands on row z * poly_stride + row_begin + j of p_coeff (N-word rows).
+        Defaults, for p_coeff [2][rows][N]: poly_stride = rows, row_begin = the limb's own index."""
+        stride = p_coeff.shape[1] if poly_stride is None else poly_stride
+        _check(lib().pha_lp_moddown_begin(self._h, chain_index, _ptr(cx), _ptr(p_coeff), p_coeff.numel() // self.n, stride,
                                           w[2] if row_begin is None else row_begin, w[2], w[3], _stream()))
 
-    def lp_moddown_finish(self, chain_index, ct, cx, p_coeff, w, p_rows=None):
-        """p_rows[k] = row of special limb k in p_coeff (default: k)"""
+    def lp_moddown_finish(self, chain_index, ct, cx, p_coeff, w, p_rows=None, poly_stride=None):
+        """p_rows[k] = row of special limb k of poly 0 in p_coeff (default: k); poly 1 is poly_stride rows further"""
         rows = None if p_rows is None else (ctypes.c_uint32 * len(p_rows))(*p_rows)
-        _check(lib().pha_lp_moddown_finish(self._h, chain_index, _ptr(ct), _ptr(cx), _ptr(p_coeff), p_coeff.shape[1], rows,
-                                           w[0], w[1], _stream()))
+        stride = p_coeff.shape[1] if poly_stride is None else poly_stride
+        _check(lib().pha_lp_moddown_finish(self._h, chain_index, _ptr(ct), _ptr(cx), _ptr(p_coeff), p_coeff.numel() // self.n,
+                                           stride, rows, w[0], w[1], _stream()))
 
     def lp_tensor_prod_2x2(self, op1, op2, result, w):
         """result [3][l][N] = op1 [2][l][N] (x) op2 [2][l][N] on the limbs [w[0], w[0] + w[1])"""

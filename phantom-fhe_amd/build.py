@@ -16,7 +16,10 @@ CMD_FILE = OUT + ".cmd"        # the command line the library was built with: ot
 
 def _command():
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    return [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", *os.environ.get("PHA_EXTRA_DEFINES", "").split(),
+    # -amdgpu-mfma-vgpr-form: bconv_mfma_kernel's accumulators land in VGPRs, where the vector ALU recombines them (no
+    # v_accvgpr_read per word; it is the only kernel with MFMA instructions)
+    return [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form",
+            *os.environ.get("PHA_EXTRA_DEFINES", "").split(),
             *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
 
 

@@ -235,7 +235,7 @@ void build_bconv_mfma_table(const uint64_t *matrix, const uint64_t *moduli, size
     out = BconvMfmaTable{};
     if (ibase == 0 || ibase > 15 || obase == 0) return;
     for (size_t j = 0; j < obase; j++)
-        if (moduli[j] <= (1ull << 32) || (moduli[j] >> 61) != 0) return;
+        if (moduli[j] < (1ull << 34) || (moduli[j] >> 61) != 0) return;
     typedef unsigned __int128 u128;
     const uint32_t ksteps = ibase <= 7 ? 1 : 2;
     const size_t quads = (obase + 3) / 4, quad_bytes = 2 * ksteps * 1024;
@@ -254,7 +254,7 @@ void build_bconv_mfma_table(const uint64_t *matrix, const uint64_t *moduli, size
     for (size_t j = 0; j < quads * 4; j++) {
         const size_t quad = j / 4, g = j % 4;
         if (j >= obase) {   // padding rows: a harmless modulus, all-zero digits
-            out.consts[j * 2] = (1ull << 33) + 1;
+            out.consts[j * 2] = (1ull << 34) + 1;
             out.consts[j * 2 + 1] = static_cast<uint64_t>((static_cast<u128>(1) << 96) / out.consts[j * 2]);
             continue;
         }

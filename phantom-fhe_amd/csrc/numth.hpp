@@ -85,8 +85,11 @@ void build_level_constants(const std::vector<uint64_t> &moduli_QP, size_t size_P
 // keep its accumulator non-negative.  Table layout, per QUAD of four outputs (j = 4 quad + g): [tile t = 0, 1][k-step]
 // [lane = 16 g' + 4 g + r][16 bytes]: the A operand of v_mfma_i32_16x16x64_i8 whose row 4 g + r is digit s = 4 t + r
 // of output j; byte jb of lane group g' is slot (input i = 8 kstep + 2 g' + jb / 8, byte a = jb % 8).
-// consts: [quads * 4][2] = {p_j, floor(2^96 / p_j)}.  ksteps = 0 (no table): ibase > 15 or a modulus <= 2^32.
-constexpr uint64_t kBmfBiasLimb = 1ull << 46;     // added to each of the two 32-bit-spaced halves of the accumulator
+// consts: [quads * 4][2] = {p_j, floor(2^96 / p_j)}.  ksteps = 0 (no table): ibase > 15 or a modulus below 2^34 (the
+// kernel's quotient estimate is then more than one short).
+constexpr uint32_t kBmfBiasWord = 1u << 30;       // what the partial sums of digits 0, 2, 4, 6 start from
+// ... which adds this much to each of the two 32-bit-spaced halves of the accumulator
+constexpr uint64_t kBmfBiasLimb = static_cast<uint64_t>(kBmfBiasWord) + (static_cast<uint64_t>(kBmfBiasWord) << 16);
 struct BconvMfmaTable {
     uint32_t ksteps = 0, quads = 0;
     std::vector<uint8_t> table;       // [quads][2][ksteps][64][16]

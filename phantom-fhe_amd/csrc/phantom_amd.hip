@@ -676,21 +676,33 @@ int launch_bconv(pha_context *ctx, uint64_t *dst, const uint64_t *y, const uint6
         // every group of quads re-reads the inputs and stages its operands in LDS (at most 60 KiB of it)
         static const uint32_t target_wgs = [] {
             const char *e = getenv("PHA_BCONV_MFMA_WGS");
-            return e ? static_cast<uint32_t>(atoi(e)) : 2048u;
+            return e ? static_cast<uint32_t>(atoi(e)) : 1024u;
+        }();
+        static const uint32_t pairs_env = [] {
+            const char *e = getenv("PHA_BCONV_MFMA_PAIRS");
+            return e ? static_cast<uint32_t>(atoi(e)) : 0u;
         }();
         const uint32_t quad_bytes = 2 * mf->ksteps * 1024 + 64, max_qpb = (60u << 10) / quad_bytes;
-        const uint32_t base = (n / 256) * batch;
-        uint32_t groups = std::min<uint32_t>(mf->quads, std::max<uint32_t>(1, (target_wgs + base - 1) / base));
+        // 256 coefficients per workgroup (128 measured slower at configs[2] even where it doubles the workgroups in flight)
+        const uint32_t pairs = pairs_env == 1 ? 1u : 2u;
+        const uint32_t coeffs = 128 * pairs, base = (n / coeffs) * batch;
+        uint32_t groups = std::min<uint32_t>(mf->quads, std::max<uint32_t>(1, target_wgs / base));
         uint32_t qpb = std::min<uint32_t>((mf->quads + groups - 1) / groups, max_qpb);
         groups = (mf->quads + qpb - 1) / qpb;
-        const dim3 g(n / 256, groups, batch);
+        const bool xcd_grid = groups > 1 && base % 8 == 0;   // see the kernel: quad groups of a block share an XCD
+        const dim3 g = xcd_grid ? dim3(base * groups) : dim3(n / coeffs, groups, batch);
         const size_t lds = static_cast<size_t>(qpb) * quad_bytes;
         // z runs over digits (each with its own matrix) only when the vector-ALU kernel's matrix advances with it
         const size_t tstride = bt.matrix_stride ? mf->table_stride : 0, cstride = bt.matrix_stride ? mf->consts_stride : 0;
-        if (mf->ksteps == 1)
-            hipLaunchKernelGGL((bconv_mfma_kernel<1>), g, dim3(256), lds, st, dst, y, mf->table.p, mf->consts.p, tstride, cstride, ibase, obase, qpb, n, skip_start, skip_len, bt);
-        else
-            hipLaunchKernelGGL((bconv_mfma_kernel<2>), g, dim3(256), lds, st, dst, y, mf->table.p, mf->consts.p, tstride, cstride, ibase, obase, qpb, n, skip_start, skip_len, bt);
+#define BM_LAUNCH(KS, PR)                                                                                                     \
+    hipLaunchKernelGGL((bconv_mfma_kernel<KS, PR>), g, dim3(256), lds, st, dst, y, mf->table.p, mf->consts.p, tstride, cstride, \
+                       ibase, obase, qpb, groups, n, skip_start, skip_len, bt)
+        if (mf->ksteps == 1) {
+            if (pairs == 1) BM_LAUNCH(1, 1); else BM_LAUNCH(1, 2);
+        } else {
+            if (pairs == 1) BM_LAUNCH(2, 1); else BM_LAUNCH(2, 2);
+        }
+#undef BM_LAUNCH
         return check_launch("bconv_mfma");
     }
     // Every output-limb group re-reads the ibase input limbs: as few groups as still give ~4096 workgroups
@@ -723,7 +735,9 @@ int launch_bconv(pha_context *ctx, uint64_t *dst, const uint64_t *y, const uint6
 }
 
 // DRNSTool::modup (src/rns_bconv.cu:530-628), t_cks = scratch [size_Ql][n]
-int do_modup(pha_context *ctx, LevelTool *lt, uint64_t *dst, const uint64_t *cks, uint64_t *t_cks, hipStream_t st) {
+// copy_own = false leaves the digits' own slots of dst unwritten: the caller's inner product reads those limbs from cks
+int do_modup(pha_context *ctx, LevelTool *lt, uint64_t *dst, const uint64_t *cks, uint64_t *t_cks, hipStream_t st,
+             bool copy_own = true) {
     const size_t n = ctx->n, size_Ql = lt->size_Ql, alpha = ctx->size_P, size_QlP = size_Ql + alpha;
     NttRange r;
     PHA_TRY(make_range(ctx, size_Ql, 0, 0, 0, 0, 0, r));
@@ -733,7 +747,7 @@ int do_modup(pha_context *ctx, LevelTool *lt, uint64_t *dst, const uint64_t *cks
         hipLaunchKernelGGL(modup_single_p_kernel, dim3(static_cast<uint32_t>(n / 256), static_cast<uint32_t>(lt->beta)),
                            dim3(256), 0, st, dst, cks, t_cks, ctx->d_mod.p, static_cast<uint32_t>(size_Ql),
                            static_cast<uint32_t>(ctx->size_Q), static_cast<uint32_t>(n), 0u,
-                           static_cast<uint32_t>(size_QlP));
+                           static_cast<uint32_t>(size_QlP), CoeffRows{});
         PHA_TRY(check_launch("modup_single_p"));
     } else {
         ep.cst = lt->partHatInv.v.p;
@@ -742,14 +756,14 @@ int do_modup(pha_context *ctx, LevelTool *lt, uint64_t *dst, const uint64_t *cks
         if (lt->uniform_digits) {
             const uint32_t obase = static_cast<uint32_t>(size_QlP - alpha);
             BconvBatch bt{size_QlP * n, alpha * n, static_cast<size_t>(obase) * alpha, obase,
-                          static_cast<uint32_t>(alpha), cks, alpha * n, 0, 0, 0};
+                          static_cast<uint32_t>(alpha), copy_own ? cks : nullptr, alpha * n, 0, 0, 0};
             PHA_TRY(launch_bconv(ctx, dst, t_cks, lt->modup_matrix_all.p, lt->modup_tidx_all.p,
                                  static_cast<uint32_t>(alpha), obase, 0, static_cast<uint32_t>(alpha),
                                  static_cast<uint32_t>(lt->beta), bt, st, &lt->modup_mfma_all));
         } else {
             for (size_t d = 0; d < lt->beta; d++) {
                 const size_t s = d * alpha, e = std::min(s + alpha, size_Ql), len = e - s;
-                BconvBatch bt{0, 0, 0, 0, 0, cks + s * n, 0, 0, 0, 0};
+                BconvBatch bt{0, 0, 0, 0, 0, copy_own ? cks + s * n : nullptr, 0, 0, 0, 0};
                 PHA_TRY(launch_bconv(ctx, dst + d * size_QlP * n, t_cks + s * n, lt->modup_matrix[d].p,
                                      lt->modup_obase_tidx[d].p, static_cast<uint32_t>(len),
                                      static_cast<uint32_t>(size_QlP - len), static_cast<uint32_t>(s),
@@ -767,14 +781,15 @@ int do_modup(pha_context *ctx, LevelTool *lt, uint64_t *dst, const uint64_t *cks
     return PHA_OK;
 }
 
+// own: the digits' own limbs (c2 in NTT form) when the modup did not copy them into t_mod_up
 int do_inner_prod(pha_context *ctx, LevelTool *lt, uint64_t *cx, const uint64_t *t_mod_up, const uint64_t *const *evks,
-                  hipStream_t st, const uint32_t *perm = nullptr) {
+                  hipStream_t st, const uint32_t *perm = nullptr, const uint64_t *own = nullptr) {
     const uint32_t n = static_cast<uint32_t>(ctx->n);
     const uint32_t size_QlP = static_cast<uint32_t>(lt->size_Ql + ctx->size_P);
     hipLaunchKernelGGL(key_switch_inner_prod_kernel, dim3(size_QlP * (n / 512)), dim3(256), 0, st, cx, t_mod_up, evks,
                        ctx->d_mod.p, n, static_cast<uint32_t>(ctx->size_QP), size_QlP,
                        static_cast<uint32_t>(ctx->size_Q), static_cast<uint32_t>(lt->size_Ql),
-                       static_cast<uint32_t>(lt->beta), 0u, perm);
+                       static_cast<uint32_t>(lt->beta), 0u, perm, own, static_cast<uint32_t>(ctx->size_P));
     return check_launch("key_switch_inner_prod");
 }
 
@@ -952,8 +967,10 @@ int do_keyswitch(pha_context *ctx, LevelTool *lt, uint64_t *ct, const uint64_t *
     PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n, &ws, st));
     WsLease ws_lease(ctx, st);
     uint64_t *t_mod_up = ws, *cx = t_mod_up + lt->beta * size_QlP * n, *scratch = cx + 2 * size_QlP * n;
-    PHA_TRY(do_modup(ctx, lt, t_mod_up, c2, scratch, st));
-    PHA_TRY(do_inner_prod(ctx, lt, cx, t_mod_up, evks, st));
+    // alpha > 1: the digits' own limbs stay in c2 and the inner product reads them there (36 MiB less traffic at configs[2])
+    const bool in_place_own = ctx->size_P > 1;
+    PHA_TRY(do_modup(ctx, lt, t_mod_up, c2, scratch, st, !in_place_own));
+    PHA_TRY(do_inner_prod(ctx, lt, cx, t_mod_up, evks, st, nullptr, in_place_own ? c2 : nullptr));
     // both polys' moddown in one launch sequence, add_to_ct fused into the NTT epilogue
     // (src/eval_key_switch.cu:157-177)
     return do_moddown(ctx, lt, ct, cx, scratch, addend ? addend : ct, 2, st, addend_every);
@@ -1013,38 +1030,62 @@ int make_p_window(const pha_context *ctx, const LevelTool *lt, const LimbWindow 
     return PHA_OK;
 }
 
-int lp_modup_begin(pha_context *ctx, LevelTool *lt, const uint64_t *c2_ntt, uint64_t *c2_coeff, const LimbWindow &w,
-                   hipStream_t st) {
+// owned limb q0 + j lands in row row_begin + j of c2_coeff (the buffer the ranks all-gather: rank r's block of rows)
+int lp_modup_begin(pha_context *ctx, LevelTool *lt, const uint64_t *c2_ntt, uint64_t *c2_coeff, size_t row_begin,
+                   const LimbWindow &w, hipStream_t st) {
     if (!w.qc) return PHA_OK;
     NttRange r;
     PHA_TRY(make_range(ctx, w.qc, w.q0, 0, 0, 0, 0, r));
     Epilogue ep{};
-    if (ctx->size_P == 1) return ntt_backward(ctx, c2_coeff, c2_ntt, 1, 0, r, EPI_NONE, ep, st);
+    // limb q0 + j -> row row_begin + j; the pointer moves up when the rows start beyond the limb index
+    uint64_t *out = c2_coeff;
+    size_t limb0 = w.q0 - row_begin;
+    if (row_begin > w.q0) {
+        out = c2_coeff + (row_begin - w.q0) * ctx->n;
+        limb0 = 0;
+    }
+    if (ctx->size_P == 1) return ntt_backward(ctx, out, c2_ntt, 1, 0, r, EPI_NONE, ep, st, 3, limb0, 0);
     ep.cst = lt->partHatInv.v.p;
     ep.cst_shoup = lt->partHatInv.s.p;
-    return ntt_backward(ctx, c2_coeff, c2_ntt, 1, 0, r, EPI_SCALE, ep, st);
+    return ntt_backward(ctx, out, c2_ntt, 1, 0, r, EPI_SCALE, ep, st, 3, limb0, 0);
 }
 
+// q_rows != nullptr: the coefficient form of limb j is row q_rows[j] of c2_coeff (rank blocks padded to equal size)
 int lp_modup_finish(pha_context *ctx, LevelTool *lt, uint64_t *t_mod_up, const uint64_t *c2_ntt, const uint64_t *c2_coeff,
-                    const LimbWindow &w, hipStream_t st) {
+                    const uint32_t *q_rows, const LimbWindow &w, hipStream_t st) {
     const size_t n = ctx->n, size_Ql = lt->size_Ql, alpha = ctx->size_P, size_QlP = size_Ql + alpha;
     const size_t win[2][2] = {{w.q0, w.q0 + w.qc}, {size_Ql + w.p0, size_Ql + w.p0 + w.pc}};
+    if (q_rows && size_Ql > kBconvMaxRows)
+        return fail(PHA_ERR_INVALID_ARGUMENT, "a c2_coeff row table holds at most %u limbs", kBconvMaxRows);
     if (alpha == 1) {
+        CoeffRows rows{};
+        if (q_rows) {
+            rows.set = 1;
+            for (size_t j = 0; j < size_Ql; j++) rows.row[j] = static_cast<uint16_t>(q_rows[j]);
+        }
         for (const auto &jw : win) {
             if (jw[0] == jw[1]) continue;
             hipLaunchKernelGGL(modup_single_p_kernel, dim3(static_cast<uint32_t>(n / 256), static_cast<uint32_t>(lt->beta)),
                                dim3(256), 0, st, t_mod_up, c2_ntt, c2_coeff, ctx->d_mod.p, static_cast<uint32_t>(size_Ql),
                                static_cast<uint32_t>(ctx->size_Q), static_cast<uint32_t>(n), static_cast<uint32_t>(jw[0]),
-                               static_cast<uint32_t>(jw[1]));
+                               static_cast<uint32_t>(jw[1]), rows);
             PHA_TRY(check_launch("modup_single_p"));
         }
     } else {
         // the launches of do_modup, restricted to the outputs (and own-limb copies) inside this rank's windows
         const uint32_t own[4] = {static_cast<uint32_t>(win[0][0]), static_cast<uint32_t>(win[0][1]), static_cast<uint32_t>(win[1][0]),
                                  static_cast<uint32_t>(win[1][1])};
-        auto owned = [&](BconvBatch bt) {
+        // first: the digit's first limb (its inputs are limbs first, first + 1, ...); stride: limbs from one digit of a
+        // batched launch to the next
+        auto owned = [&](BconvBatch bt, size_t first, size_t stride) {
             bt.own_set = 1;
             for (int i = 0; i < 4; i++) bt.own[i] = own[i];
+            if (q_rows) {
+                bt.in_rows_set = 1;
+                bt.in_row_stride = static_cast<uint32_t>(stride);
+                bt.y_stride = 0;
+                for (size_t j = first; j < size_Ql; j++) bt.in_row[j - first] = static_cast<uint16_t>(q_rows[j]);
+            }
             return bt;
         };
         if (lt->uniform_digits) {
@@ -1053,15 +1094,15 @@ int lp_modup_finish(pha_context *ctx, LevelTool *lt, uint64_t *t_mod_up, const u
                           static_cast<uint32_t>(alpha), c2_ntt, alpha * n, 0, 0, 0};
             PHA_TRY(launch_bconv(ctx, t_mod_up, c2_coeff, lt->modup_matrix_all.p, lt->modup_tidx_all.p,
                                  static_cast<uint32_t>(alpha), obase, 0, static_cast<uint32_t>(alpha),
-                                 static_cast<uint32_t>(lt->beta), owned(bt), st, &lt->modup_mfma_all));
+                                 static_cast<uint32_t>(lt->beta), owned(bt, 0, alpha), st, &lt->modup_mfma_all));
         } else {
             for (size_t d = 0; d < lt->beta; d++) {
                 const size_t s = d * alpha, e = std::min(s + alpha, size_Ql), len = e - s;
                 BconvBatch bt{0, 0, 0, 0, 0, c2_ntt + s * n, 0, 0, 0, 0};
-                PHA_TRY(launch_bconv(ctx, t_mod_up + d * size_QlP * n, c2_coeff + s * n, lt->modup_matrix[d].p,
+                PHA_TRY(launch_bconv(ctx, t_mod_up + d * size_QlP * n, q_rows ? c2_coeff : c2_coeff + s * n, lt->modup_matrix[d].p,
                                      lt->modup_obase_tidx[d].p, static_cast<uint32_t>(len),
                                      static_cast<uint32_t>(size_QlP - len), static_cast<uint32_t>(s),
-                                     static_cast<uint32_t>(len), 1, owned(bt), st, &lt->modup_mfma[d]));
+                                     static_cast<uint32_t>(len), 1, owned(bt, s, 0), st, &lt->modup_mfma[d]));
             }
         }
     }
@@ -1150,9 +1191,9 @@ int lp_moddown_finish(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *c
     } else {
         BconvBatch bt{size_Ql * n, p_stride, 0, 0, 0, nullptr, 0, 0, 0, 0};
         if (p_rows) {
-            if (alpha > 16) return fail(PHA_ERR_INVALID_ARGUMENT, "a permuted p_coeff needs at most 16 special primes");
+            if (alpha > kBconvMaxRows) return fail(PHA_ERR_INVALID_ARGUMENT, "a p_coeff row table holds at most %u special primes", kBconvMaxRows);
             bt.in_rows_set = 1;
-            for (size_t k = 0; k < alpha; k++) bt.in_row[k] = p_rows[k];
+            for (size_t k = 0; k < alpha; k++) bt.in_row[k] = static_cast<uint16_t>(p_rows[k]);
         }
         // the whole matrix with this rank's Q window as the owned outputs
         bt.own_set = 1;
@@ -1886,18 +1927,23 @@ int pha_prepare_level(pha_context *ctx, size_t chain_index) {
     const LimbWindow w{q_begin, q_count, p_begin, p_count}; \
     PHA_TRY(check_window(ctx, lt, w))
 
-int pha_lp_modup_begin(pha_context *ctx, size_t chain_index, const uint64_t *c2_ntt, uint64_t *c2_coeff, size_t q_begin,
-                       size_t q_count, pha_stream_t stream) {
+int pha_lp_modup_begin(pha_context *ctx, size_t chain_index, const uint64_t *c2_ntt, uint64_t *c2_coeff, size_t c2_coeff_rows,
+                       size_t row_begin, size_t q_begin, size_t q_count, pha_stream_t stream) {
     const size_t p_begin = 0, p_count = 0;
     LP_PROLOGUE(c2_ntt && c2_coeff);
-    return lp_modup_begin(ctx, lt, c2_ntt, c2_coeff, w, as_stream(stream));
+    if (row_begin + q_count > c2_coeff_rows) return fail(PHA_ERR_INVALID_ARGUMENT, "rows exceed c2_coeff");
+    return lp_modup_begin(ctx, lt, c2_ntt, c2_coeff, row_begin, w, as_stream(stream));
 }
 
 int pha_lp_modup_finish(pha_context *ctx, size_t chain_index, uint64_t *t_mod_up, const uint64_t *c2_ntt,
-                        const uint64_t *c2_coeff, size_t q_begin, size_t q_count, size_t p_begin, size_t p_count,
-                        pha_stream_t stream) {
+                        const uint64_t *c2_coeff, size_t c2_coeff_rows, const uint32_t *q_rows_host, size_t q_begin,
+                        size_t q_count, size_t p_begin, size_t p_count, pha_stream_t stream) {
     LP_PROLOGUE(t_mod_up && c2_ntt && c2_coeff);
-    return lp_modup_finish(ctx, lt, t_mod_up, c2_ntt, c2_coeff, w, as_stream(stream));
+    if (c2_coeff_rows < lt->size_Ql) return fail(PHA_ERR_INVALID_ARGUMENT, "c2_coeff holds fewer limbs than Q_l");
+    if (q_rows_host)
+        for (size_t j = 0; j < lt->size_Ql; j++)
+            if (q_rows_host[j] >= c2_coeff_rows) return fail(PHA_ERR_INVALID_ARGUMENT, "q_rows exceed c2_coeff");
+    return lp_modup_finish(ctx, lt, t_mod_up, c2_ntt, c2_coeff, q_rows_host, w, as_stream(stream));
 }
 
 int pha_lp_key_switch_inner_prod(pha_context *ctx, size_t chain_index, uint64_t *p_cx, const uint64_t *p_t_mod_up,
@@ -1907,23 +1953,22 @@ int pha_lp_key_switch_inner_prod(pha_context *ctx, size_t chain_index, uint64_t 
     return lp_inner_prod(ctx, lt, p_cx, p_t_mod_up, rlk, w, as_stream(stream));
 }
 
-int pha_lp_moddown_begin(pha_context *ctx, size_t chain_index, const uint64_t *cx, uint64_t *p_coeff, size_t p_coeff_poly_stride_limbs,
-                         size_t row_begin, size_t p_begin, size_t p_count, pha_stream_t stream) {
+int pha_lp_moddown_begin(pha_context *ctx, size_t chain_index, const uint64_t *cx, uint64_t *p_coeff, size_t p_coeff_rows,
+                         size_t p_coeff_poly_stride_limbs, size_t row_begin, size_t p_begin, size_t p_count, pha_stream_t stream) {
     const size_t q_begin = 0, q_count = 0;
     LP_PROLOGUE(cx && p_coeff);
-    if (row_begin + p_count > p_coeff_poly_stride_limbs) return fail(PHA_ERR_INVALID_ARGUMENT, "rows exceed p_coeff");
+    if (p_count && p_coeff_poly_stride_limbs + row_begin + p_count > p_coeff_rows) return fail(PHA_ERR_INVALID_ARGUMENT, "rows exceed p_coeff");
     return lp_moddown_begin(ctx, lt, cx, p_coeff, p_coeff_poly_stride_limbs * ctx->n, row_begin, w, as_stream(stream));
 }
 
 int pha_lp_moddown_finish(pha_context *ctx, size_t chain_index, uint64_t *ct, uint64_t *cx, const uint64_t *p_coeff,
-                          size_t p_coeff_poly_stride_limbs, const uint32_t *p_rows_host, size_t q_begin, size_t q_count,
-                          pha_stream_t stream) {
+                          size_t p_coeff_rows, size_t p_coeff_poly_stride_limbs, const uint32_t *p_rows_host, size_t q_begin,
+                          size_t q_count, pha_stream_t stream) {
     const size_t p_begin = 0, p_count = 0;
     LP_PROLOGUE(ct && cx && p_coeff);
-    if (p_coeff_poly_stride_limbs < ctx->size_P) return fail(PHA_ERR_INVALID_ARGUMENT, "p_coeff holds fewer limbs than P");
-    if (p_rows_host)
-        for (size_t k = 0; k < ctx->size_P; k++)
-            if (p_rows_host[k] >= p_coeff_poly_stride_limbs) return fail(PHA_ERR_INVALID_ARGUMENT, "p_rows exceed p_coeff");
+    for (size_t k = 0; k < ctx->size_P; k++)
+        if ((p_rows_host ? p_rows_host[k] : k) + p_coeff_poly_stride_limbs >= p_coeff_rows)
+            return fail(PHA_ERR_INVALID_ARGUMENT, "p_rows exceed p_coeff");
     return lp_moddown_finish(ctx, lt, ct, cx, p_coeff, p_coeff_poly_stride_limbs * ctx->n, p_rows_host, w, as_stream(stream));
 }
 
@@ -2283,12 +2328,13 @@ int pha_rotate_hoisted(pha_context *ctx, size_t chain_index, const uint64_t *ct,
     PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n, &ws, st));
     WsLease ws_lease(ctx, st);
     uint64_t *t_mod_up = ws, *cx = t_mod_up + lt->beta * size_QlP * n, *scratch = cx + 2 * size_QlP * n;
-    PHA_TRY(do_modup(ctx, lt, t_mod_up, ct + size_Ql * n, scratch, st));  // once for every rotation
+    const bool in_place_own = ctx->size_P > 1;   // as in do_keyswitch
+    PHA_TRY(do_modup(ctx, lt, t_mod_up, ct + size_Ql * n, scratch, st, !in_place_own));  // once for every rotation
     for (size_t r = 0; r < n_rot; r++) {
         if (!out_host[r] || !evks_host[r] || out_host[r] == ct) return fail(PHA_ERR_INVALID_ARGUMENT, "null or aliasing rotation output");
         const uint32_t *perm;
         PHA_TRY(get_galois_table(ctx, galois_elts_host[r], &perm));
-        PHA_TRY(do_inner_prod(ctx, lt, cx, t_mod_up, evks_host[r], st, perm));
+        PHA_TRY(do_inner_prod(ctx, lt, cx, t_mod_up, evks_host[r], st, perm, in_place_own ? ct + size_Ql * n : nullptr));
         PHA_TRY(do_galois(ctx, ct, size_Ql, perm, out_host[r], st));
         PHA_TRY(do_moddown(ctx, lt, out_host[r], cx, scratch, out_host[r], 2, st, 2));  // poly 0 += pi(c0), poly 1 as is
     }
@@ -2508,8 +2554,9 @@ int pha_multiply_relin_rescale(pha_context *ctx, size_t chain_index, const uint6
                                static_cast<uint32_t>(size_Ql), times2 ? 1u : 0u);
         PHA_TRY(check_launch("tensor_prod_2x2"));
     }
-    PHA_TRY(do_modup(ctx, lt, t_mod_up, d + 2 * size_Ql * n, scratch, st));
-    PHA_TRY(do_inner_prod(ctx, lt, cx, t_mod_up, relin_evks, st));
+    const bool in_place_own = ctx->size_P > 1;   // as in do_keyswitch
+    PHA_TRY(do_modup(ctx, lt, t_mod_up, d + 2 * size_Ql * n, scratch, st, !in_place_own));
+    PHA_TRY(do_inner_prod(ctx, lt, cx, t_mod_up, relin_evks, st, nullptr, in_place_own ? d + 2 * size_Ql * n : nullptr));
     const uint32_t n32 = static_cast<uint32_t>(n), ql = static_cast<uint32_t>(size_Ql), qlp = static_cast<uint32_t>(size_QlP);
     hipLaunchKernelGGL((lift_qp_kernel<false>), dim3(qlp * (n32 / 512), 2), dim3(256), 0, st, cx, d, static_cast<const uint32_t *>(nullptr),
                        ctx->d_bigP_mod_q.p, ctx->d_mod.p, n32, ql, qlp);

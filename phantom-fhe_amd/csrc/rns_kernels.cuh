@@ -17,6 +17,7 @@ namespace pha {
 // ---------------------------------------------------------------------------------------------
 // blockIdx.z batches independent conversions that share the shape (the beta digits of modup when
 // alpha divides size_Ql, or the two polys of moddown): every pointer advances by its z-stride.
+constexpr uint32_t kBconvMaxRows = 64;
 struct BconvBatch {
     size_t dst_stride, y_stride, matrix_stride, tidx_stride;
     uint32_t skip_stride;
@@ -26,10 +27,12 @@ struct BconvBatch {
     // the group strides to b (dst stays linear in z)
     uint32_t group;
     size_t y_group_stride, copy_group_stride;
-    // in_rows_set != 0: input limb i is row in_row[i] of y instead of row i (a gathered buffer whose rank blocks are
-    // not in limb order: limb-parallel moddown); register-path kernels only (ibase <= 16)
+    // in_rows_set != 0: input limb i of digit d is row in_row[d * in_row_stride + i] of y (which then does not advance
+    // with the digit: the caller sets y_stride = 0) instead of row i: a gathered buffer whose rank blocks are padded
+    // or not in limb order (limb-parallel modup and moddown); register-path kernels only (ibase <= 16)
     uint32_t in_rows_set;
-    uint32_t in_row[16];
+    uint32_t in_row_stride;
+    uint16_t in_row[kBconvMaxRows];
     // own_set != 0: only the outputs whose buffer limb jo lies in [own[0], own[1]) or [own[2], own[3]) are computed, and
     // only those of the digit's own limbs are copied (limb-parallel modup: a rank's Q window and its P window)
     uint32_t own_set;
@@ -43,8 +46,9 @@ __device__ __forceinline__ bool bconv_owned(const BconvBatch &bt, uint32_t jo) {
 __device__ __forceinline__ void bconv_batch_offsets(const BconvBatch &bt, uint32_t z, uint64_t *__restrict__ &dst,
                                                     const uint64_t *__restrict__ &y, const uint64_t *__restrict__ &matrix,
                                                     const uint32_t *__restrict__ &obase_tidx, uint32_t &skip_start,
-                                                    const uint64_t *&copy_src) {
+                                                    const uint64_t *&copy_src, uint32_t &digit) {
     const uint32_t d = bt.group ? z % bt.group : z, b = bt.group ? z / bt.group : 0;
+    digit = d;
     dst += z * bt.dst_stride;
     y += d * bt.y_stride + b * bt.y_group_stride;
     matrix += d * bt.matrix_stride;
@@ -89,7 +93,8 @@ __global__ __launch_bounds__(256) void bconv_matmul_kernel(uint64_t *__restrict_
                                                            uint32_t skip_start, uint32_t skip_len, BconvBatch bt) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     const uint64_t *src;
-    bconv_batch_offsets(bt, blockIdx.z, dst, y, matrix, obase_tidx, skip_start, src);
+    uint32_t digit;
+    bconv_batch_offsets(bt, blockIdx.z, dst, y, matrix, obase_tidx, skip_start, src, digit);
     const uint32_t j0 = blockIdx.y * limbs_per_block;
     const uint32_t j1 = min(j0 + limbs_per_block, obase_size);
     if (bt.own_set) {   // a workgroup none of whose outputs (or copies) this rank owns has nothing to read
@@ -99,7 +104,8 @@ __global__ __launch_bounds__(256) void bconv_matmul_kernel(uint64_t *__restrict_
     }
     uint64_t in[IB];
 #pragma unroll
-    for (int i = 0; i < IB; i++) in[i] = y[static_cast<size_t>(bt.in_rows_set ? bt.in_row[i] : i) * n + k];
+    for (int i = 0; i < IB; i++)
+        in[i] = y[static_cast<size_t>(bt.in_rows_set ? bt.in_row[(digit * bt.in_row_stride + i) & (kBconvMaxRows - 1)] : i) * n + k];
     if (src != nullptr && blockIdx.y == 0) {
 #pragma unroll
         for (int i = 0; i < IB; i++)
@@ -128,81 +134,109 @@ __global__ __launch_bounds__(256) void bconv_matmul_kernel(uint64_t *__restrict_
 typedef int bm_v4i __attribute__((ext_vector_type(4)));
 constexpr uint32_t kBmOperandBytes = 1024;   // one A operand: 64 lanes x 16 bytes
 
+// d0, d1: the partial sums of digits 0..3 and 4..7, registers 0 and 2 of each started at kBmfBiasWord (the MFMA's C
+// operand) so that every intermediate is a non-negative machine word
 __device__ __forceinline__ uint64_t bm_finish(const bm_v4i &d0, const bm_v4i &d1, uint64_t p, uint64_t mu) {
-    // |partial sum| < 2^21: the 32-bit halves cannot overflow, v0, v1 land in [0, 2^47)
-    const int32_t lo0 = d0.x + d0.y * 256, hi0 = d0.z + d0.w * 256;
-    const int32_t lo1 = d1.x + d1.y * 256, hi1 = d1.z + d1.w * 256;
-    const uint64_t v0 = static_cast<uint64_t>(static_cast<int64_t>(lo0) + static_cast<int64_t>(hi0) * 65536 +
-                                              static_cast<int64_t>(kBmfBiasLimb));
-    const uint64_t v1 = static_cast<uint64_t>(static_cast<int64_t>(lo1) + static_cast<int64_t>(hi1) * 65536 +
-                                              static_cast<int64_t>(kBmfBiasLimb));
-    // x = v0 + 2^32 v1 < 2^80; xh = floor(x / 2^32); qhat = floor(xh mu / 2^64) in [floor(x / p) - 2, floor(x / p)]
-    const uint64_t xh = v1 + (v0 >> 32);
-    const uint64_t xlo = (xh << 32) | lo32(v0);
+    // |partial sum| < 2^21: lo, hi in (2^29, 2^31); v = lo + 2^16 hi < 2^47.0001
+    const uint32_t lo0 = static_cast<uint32_t>(d0.x) + (static_cast<uint32_t>(d0.y) << 8);
+    const uint32_t hi0 = static_cast<uint32_t>(d0.z) + (static_cast<uint32_t>(d0.w) << 8);
+    const uint32_t lo1 = static_cast<uint32_t>(d1.x) + (static_cast<uint32_t>(d1.y) << 8);
+    const uint32_t hi1 = static_cast<uint32_t>(d1.z) + (static_cast<uint32_t>(d1.w) << 8);
+    const uint64_t v0 = mad32(hi0, 65536u, lo0), v1 = mad32(hi1, 65536u, lo1);
+    // x = v0 + 2^32 v1 < 2^80; xh = floor(x / 2^32); qhat = floor(xh mu / 2^64) is floor(x / p) or one less (p >= 2^34)
+    const uint64_t xh = v1 + hi32(v0);
+    const uint64_t xlo = pack64(lo32(v0), lo32(xh));
     const uint64_t qhat = mulhi64(xh, mu);
-    uint64_t r = xlo - qhat * p;    // < 3p < 2^63
-    r = csub(r, p << 1);
-    return csub(r, p);
+    return csub(xlo - qhat * p, p);
 }
 
-template <int KSTEPS>
+// PAIRS: 32-coefficient pairs per wave (2: a workgroup converts 256 coefficients, 1: 128)
+template <int KSTEPS, int PAIRS>
 __global__ __launch_bounds__(256) void bconv_mfma_kernel(uint64_t *__restrict__ dst, const uint64_t *__restrict__ y,
                                                          const uint8_t *__restrict__ table, const uint64_t *__restrict__ consts,
                                                          size_t table_stride, size_t consts_stride, uint32_t ibase,
-                                                         uint32_t obase, uint32_t quads_per_block, uint32_t n,
-                                                         uint32_t skip_start, uint32_t skip_len, BconvBatch bt) {
+                                                         uint32_t obase, uint32_t quads_per_block, uint32_t quad_groups,
+                                                         uint32_t n, uint32_t skip_start, uint32_t skip_len, BconvBatch bt) {
     extern __shared__ __align__(16) uint8_t bm_lds[];
-    constexpr uint32_t kQuadBytes = 2 * KSTEPS * kBmOperandBytes;
+    constexpr uint32_t kQuadBytes = 2 * KSTEPS * kBmOperandBytes, kCoeffs = 128 * PAIRS;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
-    const uint32_t z = blockIdx.z, d = bt.group ? z % bt.group : z, b = bt.group ? z / bt.group : 0;
+    // 1-D grid over (coefficient block, quad group, z).  Workgroups are dealt to the 8 XCDs round-robin: the quad
+    // groups of one (block, z) -- which read the same inputs -- are given ids 8 apart, so they share an L2 and run
+    // back to back; gridDim.y == groups when the block count is no multiple of 8 (plain 3-D grid)
+    uint32_t bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
+    if (gridDim.y == 1 && quad_groups > 1) {
+        const uint32_t xcd = blockIdx.x & 7, t = blockIdx.x >> 3, unit = (t / quad_groups) * 8 + xcd, per_z = n / kCoeffs;
+        by = t % quad_groups;
+        z = unit / per_z;
+        bx = unit % per_z;
+    }
+    const uint32_t d = bt.group ? z % bt.group : z, b = bt.group ? z / bt.group : 0;
     dst += z * bt.dst_stride;
     y += d * bt.y_stride + b * bt.y_group_stride;
     table += d * table_stride;
     consts += d * consts_stride;
     skip_start += d * bt.skip_stride;
     const uint64_t *src = bt.copy_src ? bt.copy_src + d * bt.copy_stride + b * bt.copy_group_stride : nullptr;
-    const uint32_t quads = (obase + 3) >> 2, q0 = blockIdx.y * quads_per_block, nq = min(quads_per_block, quads - q0);
-    const bool copies = src != nullptr && blockIdx.y == 0;
+    const uint32_t quads = (obase + 3) >> 2, q0 = by * quads_per_block, nq = min(quads_per_block, quads - q0);
+    const bool copies = src != nullptr && by == 0;
     if (bt.own_set) {   // a workgroup none of whose outputs (or copies) this rank owns has nothing to do
         bool any = copies && skip_start < bt.own[1] && skip_start + ibase > bt.own[0];
         for (uint32_t j = q0 * 4; j < min((q0 + nq) * 4, obase) && !any; j++) any = bconv_owned(bt, j + (j >= skip_start ? skip_len : 0));
         if (!any) return;
     }
-    // A operands and constants of this workgroup's quads
-    {
-        const uint4 *tsrc = reinterpret_cast<const uint4 *>(table + static_cast<size_t>(q0) * kQuadBytes);
-        uint4 *tdst = reinterpret_cast<uint4 *>(bm_lds);
-        for (uint32_t i = tid; i < nq * (kQuadBytes / 16); i += 256) tdst[i] = tsrc[i];
-        const uint4 *csrc = reinterpret_cast<const uint4 *>(consts) + q0 * 4;
-        uint4 *cdst = reinterpret_cast<uint4 *>(bm_lds + static_cast<size_t>(quads_per_block) * kQuadBytes);
-        for (uint32_t i = tid; i < nq * 4; i += 256) cdst[i] = csrc[i];
-    }
     // the inputs: ld[kstep][pair][h] = coefficients k0 + 32 pair + {0, 1} of input 8 kstep + 2 g + h, bytes biased by -128
-    const uint32_t k0 = blockIdx.x * 256 + wave * 64 + 2 * c;
-    bm_v4i ld[KSTEPS][2][2];
+    const uint32_t k0 = bx * kCoeffs + wave * (32 * PAIRS) + 2 * c;
+    bm_v4i ld[KSTEPS][PAIRS][2];
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ks++)
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const uint32_t i = ks * 8 + 2 * g + h;
-            const uint32_t row = bt.in_rows_set ? bt.in_row[min(i, 15u)] : i;
+            const uint32_t row = bt.in_rows_set ? bt.in_row[(d * bt.in_row_stride + i) & (kBconvMaxRows - 1)] : i;
 #pragma unroll
-            for (int pr = 0; pr < 2; pr++) {
+            for (int pr = 0; pr < PAIRS; pr++) {
                 bm_v4i v = {0, 0, 0, 0};
-                if (i < ibase) {
-                    v = *reinterpret_cast<const bm_v4i *>(y + static_cast<size_t>(row) * n + k0 + 32 * pr);
-                    v ^= static_cast<int>(0x80808080u);
-                } else if (i == ibase) {
-                    v.x = 1;   // the constant slot (both coefficients of the pair: words 0 and 2)
-                    v.z = 1;
-                }
+                if (i < ibase) v = *reinterpret_cast<const bm_v4i *>(y + static_cast<size_t>(row) * n + k0 + 32 * pr);
                 ld[ks][pr][h] = v;
             }
         }
+    // A operands and constants of this workgroup's quads: every load issued before the first LDS store
+    {
+        const uint4 *tsrc = reinterpret_cast<const uint4 *>(table + static_cast<size_t>(q0) * kQuadBytes);
+        uint4 *tdst = reinterpret_cast<uint4 *>(bm_lds);
+        const uint32_t total = nq * (kQuadBytes / 16);
+        for (uint32_t i0 = tid; i0 < total; i0 += 256 * 4) {   // loads clamped, stores predicated: all four in flight at once
+            const uint32_t i1 = i0 + 256, i2 = i0 + 512, i3 = i0 + 768, last = total - 1;
+            const uint4 v0 = tsrc[i0], v1 = tsrc[min(i1, last)], v2 = tsrc[min(i2, last)], v3 = tsrc[min(i3, last)];
+            tdst[i0] = v0;
+            if (i1 < total) tdst[i1] = v1;
+            if (i2 < total) tdst[i2] = v2;
+            if (i3 < total) tdst[i3] = v3;
+        }
+        const uint4 *csrc = reinterpret_cast<const uint4 *>(consts) + q0 * 4;
+        uint4 *cdst = reinterpret_cast<uint4 *>(bm_lds + static_cast<size_t>(quads_per_block) * kQuadBytes);
+        for (uint32_t i = tid; i < nq * 4; i += 256) cdst[i] = csrc[i];
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t i = ks * 8 + 2 * g + h;
+#pragma unroll
+            for (int pr = 0; pr < PAIRS; pr++) {
+                if (i < ibase) {
+                    ld[ks][pr][h] ^= static_cast<int>(0x80808080u);
+                } else if (i == ibase) {   // the constant slot (both coefficients of the pair: words 0 and 2)
+                    ld[ks][pr][h].x = 1;
+                    ld[ks][pr][h].z = 1;
+                }
+            }
+        }
     if (copies) {   // the digit's own limbs, already in NTT form (src/rns_bconv.cu:522-528)
-        for (uint32_t i = tid >> 7; i < ibase; i += 2)
+        constexpr uint32_t kChunks = kCoeffs / 2, kRowsPerPass = 256 / kChunks;
+        for (uint32_t i = tid / kChunks; i < ibase; i += kRowsPerPass)
             if (bconv_owned(bt, skip_start + i)) {
-                const size_t off = static_cast<size_t>(blockIdx.x) * 256 + (tid & 127) * 2;
+                const size_t off = static_cast<size_t>(bx) * kCoeffs + (tid % kChunks) * 2;
                 *reinterpret_cast<uint4 *>(dst + static_cast<size_t>(skip_start + i) * n + off) =
                     *reinterpret_cast<const uint4 *>(src + static_cast<size_t>(i) * n + off);
             }
@@ -221,11 +255,11 @@ __global__ __launch_bounds__(256) void bconv_mfma_kernel(uint64_t *__restrict__ 
         const uint32_t j = (q0 + q) * 4 + g, jo = j + (j >= skip_start ? skip_len : 0);
         const bool store = j < obase && bconv_owned(bt, jo);
 #pragma unroll
-        for (int pr = 0; pr < 2; pr++) {
+        for (int pr = 0; pr < PAIRS; pr++) {
             uint64_t out[2];
 #pragma unroll
             for (int e = 0; e < 2; e++) {
-                bm_v4i d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
+                bm_v4i d0 = {static_cast<int>(kBmfBiasWord), 0, static_cast<int>(kBmfBiasWord), 0}, d1 = d0;
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ks++) {
                     const bm_v4i bop = {ld[ks][pr][0][2 * e], ld[ks][pr][0][2 * e + 1], ld[ks][pr][1][2 * e], ld[ks][pr][1][2 * e + 1]};
@@ -289,7 +323,8 @@ __global__ __launch_bounds__(256) void bconv_matmul_generic_kernel(uint64_t *dst
                                                                    BconvBatch bt) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     const uint64_t *src;
-    bconv_batch_offsets(bt, blockIdx.z, dst, y, matrix, obase_tidx, skip_start, src);
+    uint32_t digit;
+    bconv_batch_offsets(bt, blockIdx.z, dst, y, matrix, obase_tidx, skip_start, src, digit);
     if (src != nullptr && blockIdx.y == 0) {
         for (uint32_t i = 0; i < ibase_size; i++)
             if (bconv_owned(bt, skip_start + i)) dst[static_cast<size_t>(skip_start + i) * n + k] = src[static_cast<size_t>(i) * n + k];
@@ -301,7 +336,10 @@ __global__ __launch_bounds__(256) void bconv_matmul_generic_kernel(uint64_t *dst
         if (!bconv_owned(bt, jo)) continue;
         const uint64_t *row = matrix + static_cast<size_t>(j) * ibase_size;
         u128_t acc = {0, 0};
-        for (uint32_t i = 0; i < ibase_size; i++) add128(acc, mul64x64(y[static_cast<size_t>(i) * n + k], row[i]));
+        for (uint32_t i = 0; i < ibase_size; i++) {
+            const uint32_t r = bt.in_rows_set ? bt.in_row[(digit * bt.in_row_stride + i) & (kBconvMaxRows - 1)] : i;
+            add128(acc, mul64x64(y[static_cast<size_t>(r) * n + k], row[i]));
+        }
         const DModulus m = obase_mod[obase_tidx[j]];
         dst[static_cast<size_t>(jo) * n + k] = barrett128(acc, m);
     }
@@ -309,14 +347,19 @@ __global__ __launch_bounds__(256) void bconv_matmul_generic_kernel(uint64_t *dst
 
 // alpha == 1 modup (src/rns_bconv.cu:432-453): every digit is one limb; dst[d][j][k] is the raw
 // NTT-form limb for j == d and (coeff mod p_j) otherwise.
+// rows.set != 0: the coefficient form of limb d is row rows.row[d] of cks_coeff (a gathered, padded buffer)
+struct CoeffRows {
+    uint32_t set;
+    uint16_t row[kBconvMaxRows];
+};
 __global__ __launch_bounds__(256) void modup_single_p_kernel(uint64_t *dst, const uint64_t *cks_ntt,
                                                              const uint64_t *cks_coeff, const DModulus *mod,
                                                              uint32_t size_Ql, uint32_t size_Q, uint32_t n,
-                                                             uint32_t j_begin, uint32_t j_end) {
+                                                             uint32_t j_begin, uint32_t j_end, CoeffRows rows) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     const uint32_t d = blockIdx.y;
     const uint32_t size_QlP = size_Ql + 1;
-    const uint64_t coeff = cks_coeff[static_cast<size_t>(d) * n + k];
+    const uint64_t coeff = cks_coeff[static_cast<size_t>(rows.set ? rows.row[d & (kBconvMaxRows - 1)] : d) * n + k];
     const uint64_t in_prime = mod[d].value;
     uint64_t *o = dst + static_cast<size_t>(d) * size_QlP * n + k;
     for (uint32_t j = j_begin; j < j_end; j++) {  // output limbs [j_begin, j_end) of [0, size_QlP)
@@ -356,7 +399,8 @@ __global__ __launch_bounds__(256) void key_switch_inner_prod_kernel(uint64_t *ds
                                                                     const uint64_t *const *evks, const DModulus *mod,
                                                                     uint32_t n, uint32_t size_QP, uint32_t size_QlP,
                                                                     uint32_t size_Q, uint32_t size_Ql, uint32_t beta,
-                                                                    uint32_t limb0, const uint32_t *perm = nullptr) {
+                                                                    uint32_t limb0, const uint32_t *perm = nullptr,
+                                                                    const uint64_t *own = nullptr, uint32_t alpha = 0) {
     const uint32_t per_limb = n / 512;
     const uint32_t nid = limb0 + blockIdx.x / per_limb;  // limbs [limb0, limb0 + gridDim.x / per_limb)
     const uint32_t k = ((blockIdx.x % per_limb) * 256 + threadIdx.x) * 2;
@@ -366,12 +410,15 @@ __global__ __launch_bounds__(256) void key_switch_inner_prod_kernel(uint64_t *ds
     const size_t evk_id = static_cast<size_t>(twr) * n + k;
     const size_t size_QlP_n = static_cast<size_t>(size_QlP) * n, size_QP_n = static_cast<size_t>(size_QP) * n;
     u128_t a0x = {0, 0}, a0y = {0, 0}, a1x = {0, 0}, a1y = {0, 0};
+    // own != nullptr: the modup left the digits' own limbs where they were (own [size_Ql][n], NTT form) instead of
+    // copying them into t_mod_up (src/rns_bconv.cu:522-528): limb nid of digit nid / alpha is read from there
+    const uint32_t own_digit = own != nullptr && nid < size_Ql ? nid / alpha : ~0u;
     for (uint32_t d = 0; d < beta; d++) {
         ulonglong2 t;
+        const uint64_t *row = d == own_digit ? own + static_cast<size_t>(nid) * n : t_mod_up + d * size_QlP_n + static_cast<size_t>(nid) * n;
         if (perm == nullptr) {
-            t = *reinterpret_cast<const ulonglong2 *>(t_mod_up + d * size_QlP_n + c2_id);
+            t = *reinterpret_cast<const ulonglong2 *>(row + k);
         } else {  // hoisted rotation: the automorphism is applied to t_mod_up on the fly (index gather)
-            const uint64_t *row = t_mod_up + d * size_QlP_n + static_cast<size_t>(nid) * n;
             t.x = row[perm[k]];
             t.y = row[perm[k + 1]];
         }

@@ -20,14 +20,18 @@ Each rank keeps buffers in the single-GPU layouts and reads/writes only its limb
 ``pha_lp_*`` and a ciphertext stays limb-sharded between operations.  Results on the owned limbs
 are bit-identical to the single-GPU path.
 
-Windows are EQUAL contiguous blocks: rank r owns Q limbs [r*bq, (r+1)*bq) with bq = ceil(l / G) (the last blocks are
-short or empty) and the special limbs of block G-1-r (reversed, so that the ranks left without Q limbs take P limbs).
-With equal blocks an all-gather needs no packing: every rank's ``all_gather_into_tensor`` input IS block `rank` of the
-output (in place).  The gathered c2 buffer [G*bq][N] then holds limb j at row j; the gathered P buffer holds special
-limb k at row p_rows[k] = (G-1 - k // bp) * bp + k % bp (blocks in rank order, ownership reversed), and the base
-conversion of the moddown reads its inputs through that row table, so nothing is repacked on either side.
-Exchange buffers are allocated once per (level, shape) and reused.  Messages are tiny by xGMI standards (18 MiB + 12 MiB in
-total at N=2^16, l=36, alpha=12), so one all-gather per buffer, padded to the block size, is the right granularity.
+Ownership is BALANCED over Q_l u P: rank r owns q_r = floor(l / G) + [r < l mod G] consecutive Q limbs and
+p_r = t_r - q_r consecutive special limbs, t_r = floor((l + alpha) / G) + [r < (l + alpha) mod G], so every rank carries
+ceil((l + alpha) / G) limbs or one less (36 + 12 limbs on 8 ranks: 5 + 1 on ranks 0-3, 4 + 2 on ranks 4-7), and both
+kinds of limb are spread over all ranks, which keeps every all-gather block small (a rank holding all of P would have
+to send it whole over each of its links).
+Exchange buffers are rank-blocked and padded: rank r's block is rows [r * b, (r + 1) * b) with b the largest window, so
+every rank's ``all_gather_into_tensor`` input IS block `rank` of the output (in place, no packing) and the consumers
+read "limb -> row" through a table (q_rows, p_rows): c2_coeff [G * bq][N]; p_coeff [G][2][bp][N] with both polys of a
+rank in one block, so the moddown needs ONE all-gather.  A key switch is two collectives and nothing between them can
+overlap them: each feeds the step right behind it (base conversion needs every input limb).
+Exchange buffers are allocated once per (level, shape) and reused.  Messages are small by xGMI standards (at N=2^16, l=36,
+alpha=12, G=8: blocks of 2.5 MiB and 2 MiB), so one all-gather per exchange is the right granularity.
 """
 import threading
 
@@ -35,22 +39,32 @@ import torch
 
 
 def block(total, parts, index):
-    """Equal-block partition of range(total): (begin, count, block) of block `index`; block = ceil(total / parts)."""
-    b = -(-total // parts) if total else 0
-    lo = min(index * b, total)
-    return lo, min(b, total - lo), b
+    """Balanced partition of range(total): (begin, count, largest count) of part `index` (the first total % parts parts
+    hold one more)."""
+    base, extra = divmod(total, parts)
+    lo = index * base + min(index, extra)
+    return lo, base + (1 if index < extra else 0), base + (1 if extra else 0)
+
+
+def limb_windows(size_ql, alpha, world):
+    """[(q_begin, q_count, p_begin, p_count)] per rank at a level with size_ql Q limbs: balanced totals, see above."""
+    wins, p0 = [], 0
+    for r in range(world):
+        q0, qc, _ = block(size_ql, world, r)
+        pc = block(size_ql + alpha, world, r)[1] - qc
+        wins.append((q0, qc, p0, pc))
+        p0 += pc
+    assert p0 == alpha and all(w[3] >= 0 for w in wins)
+    return wins
 
 
 def limb_window(size_ql, alpha, world, rank):
-    """(q_begin, q_count, p_begin, p_count) owned by `rank` at a level with size_ql Q limbs."""
-    q0, qc, _ = block(size_ql, world, rank)
-    p0, pc, _ = block(alpha, world, world - 1 - rank)
-    return q0, qc, p0, pc
+    return limb_windows(size_ql, alpha, world)[rank]
 
 
 class TorchDistComm:
     """Exchange over torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" is staged through host memory and is
-    there for tests).  `reverse` selects the group whose rank order is reversed."""
+    there for tests)."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -64,6 +78,8 @@ class TorchDistComm:
         """buf [world * rows][...]: this rank's block (rows [rank*rows, (rank+1)*rows)) goes to every rank; in place."""
         if self.world == 1:
             return
+        # the in-place form relies on block k sitting at element offset k * rows * row_size of one contiguous buffer
+        assert buf.is_contiguous() and buf.shape[0] == self.world * rows, (tuple(buf.shape), self.world, rows)
         k = self.rank
         if self.staged and buf.is_cuda:
             h = buf.cpu()
@@ -98,6 +114,7 @@ class ThreadComm:
     def all_gather_blocks(self, buf, rows):
         if self.world == 1:
             return
+        assert buf.is_contiguous() and buf.shape[0] == self.world * rows, (tuple(buf.shape), self.world, rows)
         s = self.shared
         k = self.rank
         s.slots[k] = buf[k * rows:(k + 1) * rows].clone()
@@ -128,21 +145,24 @@ class LimbParallelEvaluator:
         self._bufs = {}
 
     def windows(self, chain_index):
-        size_ql = self.ctx.size_Ql(chain_index)
-        return [limb_window(size_ql, self.ctx.size_P, self.world, r) for r in range(self.world)]
+        return limb_windows(self.ctx.size_Ql(chain_index), self.ctx.size_P, self.world)
 
     def _buffers(self, chain_index, device):
-        """Exchange and scratch buffers of a level, allocated once: c2_coeff [G*bq][N] (limb j at row j), p_coeff
-        [2][G*bp][N], t_mod_up, cx."""
+        """Exchange and scratch buffers of a level, allocated once: c2_coeff [G*bq][N], p_coeff [G*2*bp][N] (rank-blocked,
+        both polys of a rank in its block), their "limb -> row" tables, t_mod_up, cx."""
         key = (chain_index, str(device))
         b = self._bufs.get(key)
         if b is None:
             ctx = self.ctx
             size_ql, alpha, n = ctx.size_Ql(chain_index), ctx.size_P, ctx.n
-            bq, bp = block(size_ql, self.world, 0)[2], block(alpha, self.world, 0)[2]
+            wins = self.windows(chain_index)
+            bq, bp = max(w[1] for w in wins), max(w[3] for w in wins)
             mk = lambda *shape: torch.empty(shape, dtype=torch.int64, device=device)  # noqa: E731
-            p_rows = [(self.world - 1 - k // bp) * bp + k % bp for k in range(alpha)]
-            b = {"bq": bq, "bp": bp, "p_rows": p_rows, "c2_coeff": mk(self.world * bq, n), "p_coeff": mk(2, self.world * bp, n),
+            q_rows = [r * bq + i for r, w in enumerate(wins) for i in range(w[1])]
+            p_rows = [r * 2 * bp + i for r, w in enumerate(wins) for i in range(w[3])]
+            assert len(q_rows) == size_ql and len(p_rows) == alpha
+            b = {"bq": bq, "bp": bp, "q_rows": q_rows, "p_rows": p_rows, "c2_coeff": mk(self.world * bq, n),
+                 "p_coeff": mk(self.world * 2 * bp, n),
                  "t_mod_up": mk(ctx.beta(chain_index), size_ql + alpha, n), "cx": mk(2, size_ql + alpha, n)}
             self._bufs[key] = b
         return b
@@ -153,15 +173,14 @@ class LimbParallelEvaluator:
         ctx = self.ctx
         w = self.windows(chain_index)[self.rank]
         b = self._buffers(chain_index, ct.device)
-        ctx.lp_modup_begin(chain_index, c2, b["c2_coeff"], w)
-        self.comm.all_gather_blocks(b["c2_coeff"], b["bq"])
-        ctx.lp_modup_finish(chain_index, b["t_mod_up"], c2, b["c2_coeff"], w)
+        bq, bp = b["bq"], b["bp"]
+        ctx.lp_modup_begin(chain_index, c2, b["c2_coeff"], w, row_begin=self.rank * bq)
+        self.comm.all_gather_blocks(b["c2_coeff"], bq)
+        ctx.lp_modup_finish(chain_index, b["t_mod_up"], c2, b["c2_coeff"], w, q_rows=b["q_rows"])
         ctx.lp_key_switch_inner_prod(chain_index, b["cx"], b["t_mod_up"], evk, w)
-        ctx.lp_moddown_begin(chain_index, b["cx"], b["p_coeff"], w, row_begin=self.rank * b["bp"])
-        # the two polys' P limbs: one in-place all-gather each
-        self.comm.all_gather_blocks(b["p_coeff"][0], b["bp"])
-        self.comm.all_gather_blocks(b["p_coeff"][1], b["bp"])
-        ctx.lp_moddown_finish(chain_index, ct, b["cx"], b["p_coeff"], w, p_rows=b["p_rows"])
+        ctx.lp_moddown_begin(chain_index, b["cx"], b["p_coeff"], w, row_begin=self.rank * 2 * bp, poly_stride=bp)
+        self.comm.all_gather_blocks(b["p_coeff"], 2 * bp)       # both polys' P limbs in one collective
+        ctx.lp_moddown_finish(chain_index, ct, b["cx"], b["p_coeff"], w, p_rows=b["p_rows"], poly_stride=bp)
 
     def multiply_and_relin(self, chain_index, ct1, ct2, evk, out3):
         """HMult + relinearise on the owned limbs (src/evaluate.cu:229-280,553-583): out3 [3][l][N] receives the tensor
@@ -202,11 +221,15 @@ class LimbParallelEvaluator:
         """All-gather the owned Q windows of the given [limbs][N] polys so that every rank holds
         them whole (hand-off to a single-GPU consumer, tests).  size_ql: limb count of `polys` if
         it differs from the level's (after a rescale the partition is still the source level's)."""
-        full = self.ctx.size_Ql(chain_index)
-        bq = block(full, self.world, 0)[2]
+        wins = self.windows(chain_index)
+        bq = max(w[1] for w in wins)
         limit = polys[0].shape[0] if size_ql is None else size_ql
+        q0, qc = wins[self.rank][:2]
+        mine = max(0, min(qc, limit - q0))
         for pl in polys:
             pad = torch.zeros((self.world * bq, pl.shape[-1]), dtype=pl.dtype, device=pl.device)
-            pad[:limit] = pl[:limit]
+            pad[self.rank * bq:self.rank * bq + mine] = pl[q0:q0 + mine]
             self.comm.all_gather_blocks(pad, bq)
-            pl[:limit] = pad[:limit]
+            for r, (r0, rc, _, _) in enumerate(wins):
+                cnt = max(0, min(rc, limit - r0))
+                pl[r0:r0 + cnt] = pad[r * bq:r * bq + cnt]

@@ -21,21 +21,25 @@ static uint64_t rnd() {
 }
 
 static uint64_t finish(const int32_t d0[4], const int32_t d1[4], uint64_t p, uint64_t mu) {
-    const int32_t lo0 = d0[0] + d0[1] * 256, hi0 = d0[2] + d0[3] * 256, lo1 = d1[0] + d1[1] * 256, hi1 = d1[2] + d1[3] * 256;
-    const uint64_t v0 = static_cast<uint64_t>(static_cast<int64_t>(lo0) + static_cast<int64_t>(hi0) * 65536 + static_cast<int64_t>(kBmfBiasLimb));
-    const uint64_t v1 = static_cast<uint64_t>(static_cast<int64_t>(lo1) + static_cast<int64_t>(hi1) * 65536 + static_cast<int64_t>(kBmfBiasLimb));
-    if ((v0 >> 47) || (v1 >> 47)) {
-        printf("accumulator half out of range\n");
-        exit(1);
-    }
+    // the kernel's bm_finish; registers 0 and 2 of each accumulator start at kBmfBiasWord
+    const uint32_t b = kBmfBiasWord;
+    const uint32_t lo0 = static_cast<uint32_t>(d0[0]) + b + (static_cast<uint32_t>(d0[1]) << 8);
+    const uint32_t hi0 = static_cast<uint32_t>(d0[2]) + b + (static_cast<uint32_t>(d0[3]) << 8);
+    const uint32_t lo1 = static_cast<uint32_t>(d1[0]) + b + (static_cast<uint32_t>(d1[1]) << 8);
+    const uint32_t hi1 = static_cast<uint32_t>(d1[2]) + b + (static_cast<uint32_t>(d1[3]) << 8);
+    for (uint32_t w : {lo0, hi0, lo1, hi1})
+        if (w <= (1u << 29) || w >= (1u << 31)) {
+            printf("accumulator word out of range\n");
+            exit(1);
+        }
+    const uint64_t v0 = static_cast<uint64_t>(hi0) * 65536 + lo0, v1 = static_cast<uint64_t>(hi1) * 65536 + lo1;
     const uint64_t xh = v1 + (v0 >> 32), xlo = (xh << 32) | static_cast<uint32_t>(v0);
     const uint64_t qhat = static_cast<uint64_t>((static_cast<u128>(xh) * mu) >> 64);
     uint64_t r = xlo - qhat * p;
-    if (r >= 3 * p) {
+    if (r >= 2 * p) {
         printf("remainder estimate out of range\n");
         exit(1);
     }
-    if (r >= 2 * p) r -= 2 * p;
     if (r >= p) r -= p;
     return r;
 }
@@ -104,16 +108,16 @@ int main() {
     int bad = 0;
     const size_t shapes[][2] = {{1, 5}, {2, 7}, {3, 4}, {7, 9}, {8, 13}, {12, 36}, {13, 35}, {15, 6}};
     for (const auto &s : shapes) {
-        bad += run_case(s[0], s[1], 33, 61);
+        bad += run_case(s[0], s[1], 35, 61);
         bad += run_case(s[0], s[1], 61, 61);
-        bad += run_case(s[0], s[1], 34, 36);
+        bad += run_case(s[0], s[1], 35, 36);
     }
     BconvMfmaTable t;
-    std::vector<uint64_t> m(16 * 2, 1), p = {(1ull << 40) + 15, (1ull << 32) - 5};
+    std::vector<uint64_t> m(16 * 2, 1), p = {(1ull << 40) + 15, (1ull << 34) - 41};
     build_bconv_mfma_table(m.data(), p.data(), 16, 2, t);
     if (t.ksteps) bad++, printf("ibase 16 must have no table\n");
     build_bconv_mfma_table(m.data(), p.data(), 4, 2, t);
-    if (t.ksteps) bad++, printf("a modulus below 2^32 must have no table\n");
+    if (t.ksteps) bad++, printf("a modulus below 2^34 must have no table\n");
     printf(bad ? "FAILED (%d)\n" : "ok\n", bad);
     return bad ? 1 : 0;
 }

@@ -72,16 +72,17 @@ def test_bench_gpus_flag_launches_ranks():
 
 def test_limb_windows_tile_the_basis():
     sys.path.insert(0, ROOT)
-    from phantom_fhe_amd.limb_parallel import limb_window
-    for size_ql, alpha in ((36, 12), (35, 12), (6, 2), (5, 3), (1, 1), (3, 1)):
+    from phantom_fhe_amd.limb_parallel import limb_windows
+    for size_ql, alpha in ((36, 12), (35, 12), (6, 2), (5, 3), (1, 1), (3, 1), (20, 4)):
         for world in (1, 2, 3, 4, 8):
-            wins = [limb_window(size_ql, alpha, world, r) for r in range(world)]
-            assert sorted(l for q0, qc, _, _ in wins for l in range(q0, q0 + qc)) == list(range(size_ql))
-            assert sorted(l for _, _, p0, pc in wins for l in range(p0, p0 + pc)) == list(range(alpha))
-            # equal blocks: every window but the last non-empty one has the block size, so an all-gather lands in place
-            bq = -(-size_ql // world)
-            assert all(qc == bq or q0 + qc == size_ql for q0, qc, _, _ in wins)
-            assert all(q0 == min(r * bq, size_ql) for r, (q0, _, _, _) in enumerate(wins))
+            wins = limb_windows(size_ql, alpha, world)
+            assert [l for q0, qc, _, _ in wins for l in range(q0, q0 + qc)] == list(range(size_ql))   # contiguous, in rank order
+            assert [l for _, _, p0, pc in wins for l in range(p0, p0 + pc)] == list(range(alpha))
+            # balanced: every rank carries ceil((l + alpha) / G) limbs or one less, and the Q limbs alone are balanced too
+            tot = [qc + pc for _, qc, _, pc in wins]
+            assert max(tot) == -(-(size_ql + alpha) // world) and max(tot) - min(tot) <= 1
+            assert max(w[1] for w in wins) - min(w[1] for w in wins) <= 1
+    assert limb_windows(36, 12, 8)[0] == (0, 5, 0, 1) and limb_windows(36, 12, 8)[7] == (32, 4, 10, 2)
 
 
 def test_limb_parallel_exchange_world_size_2_gloo(tmp_path):
@@ -93,7 +94,7 @@ def test_limb_parallel_exchange_world_size_2_gloo(tmp_path):
         import sys
         sys.path.insert(0, {ROOT!r})
         import torch, torch.distributed as dist
-        from phantom_fhe_amd.limb_parallel import LimbParallelEvaluator, TorchDistComm, limb_window
+        from phantom_fhe_amd.limb_parallel import LimbParallelEvaluator, TorchDistComm
         dist.init_process_group("gloo")
         comm = TorchDistComm()
         assert comm.world == 2 and comm.staged
@@ -103,19 +104,27 @@ def test_limb_parallel_exchange_world_size_2_gloo(tmp_path):
             def size_Ql(self, chain_index): return 6 - chain_index
         ev = LimbParallelEvaluator(Ctx(), comm)
         wins = ev.windows(1)
-        assert wins == [(0, 3, 2, 1), (3, 2, 0, 2)]                   # equal blocks: bq = 3, bp = 2, P reversed
-        full = torch.arange(6 * 8, dtype=torch.int64).reshape(6, 8) + 1    # padded to world * bq = 6 rows
+        assert wins == [(0, 3, 0, 1), (3, 2, 1, 2)]                   # balanced: 4 limbs each
+        full = torch.arange(5 * 8, dtype=torch.int64).reshape(5, 8) + 1
         q0, qc, p0, pc = wins[comm.rank]
-        mine = torch.zeros_like(full)
-        mine[q0:q0 + qc] = full[q0:q0 + qc]
-        comm.all_gather_blocks(mine, 3)                                # in place, ragged last block (3 + 2)
-        assert torch.equal(mine[:5], full[:5])
-        plimbs = torch.arange(3 * 8, dtype=torch.int64).reshape(3, 8) + 100 # the three special limbs
-        pm = torch.zeros(4, 8, dtype=torch.int64)                           # world * bp = 4 rows, blocks in rank order
-        pm[comm.rank * 2:comm.rank * 2 + pc] = plimbs[p0:p0 + pc]           # what lp_moddown_begin(row_begin=rank*bp) does
-        comm.all_gather_blocks(pm, 2)
-        p_rows = [(2 - 1 - k // 2) * 2 + k % 2 for k in range(3)]           # the row table lp_moddown_finish reads by
-        assert p_rows == [2, 3, 0] and torch.equal(pm[p_rows], plimbs)
+        bq, bp = 3, 2                                                  # the largest windows: block sizes of the exchanges
+        mine = torch.zeros(2 * bq, 8, dtype=torch.int64)               # rank-blocked, padded: rank r's limbs from row r * bq
+        mine[comm.rank * bq:comm.rank * bq + qc] = full[q0:q0 + qc]    # what lp_modup_begin(row_begin=rank*bq) does
+        comm.all_gather_blocks(mine, bq)
+        q_rows = [0, 1, 2, 3, 4]                                       # rank 1's block starts at row 3 = its first limb here
+        assert torch.equal(mine[q_rows], full)
+        plimbs = torch.arange(2 * 3 * 8, dtype=torch.int64).reshape(2, 3, 8) + 100   # [poly][special limb]
+        pm = torch.zeros(2 * 2 * bp, 8, dtype=torch.int64)             # [rank][poly][bp] rows: ONE gather for both polys
+        for poly in range(2):                                          # what lp_moddown_begin(row_begin=rank*2*bp, poly_stride=bp) does
+            pm[comm.rank * 2 * bp + poly * bp:comm.rank * 2 * bp + poly * bp + pc] = plimbs[poly, p0:p0 + pc]
+        comm.all_gather_blocks(pm, 2 * bp)
+        p_rows = [0, 4, 5]                                             # the row table lp_moddown_finish reads poly 0 by
+        assert torch.equal(pm[p_rows], plimbs[0]) and torch.equal(pm[[r + bp for r in p_rows]], plimbs[1])
+        try:
+            comm.all_gather_blocks(pm[:, ::2], 2 * bp)                 # a strided view must be refused, not gathered wrongly
+            raise SystemExit("non-contiguous buffer accepted")
+        except AssertionError:
+            pass
         last = full[4].clone() if comm.rank == 0 else torch.zeros(8, dtype=torch.int64)
         comm.broadcast(last, 0)
         assert torch.equal(last, full[4])

@@ -52,7 +52,7 @@ def _uniform_evk(o, seed):
 
 
 @pytest.mark.parametrize("world,size_p,chain_index", [(2, 2, 1), (3, 2, 2), (8, 2, 1), (4, 1, 1), (3, 3, 1), (2, 3, 3),
-                                                      (5, 1, 4)])
+                                                      (5, 1, 4), (4, 3, 2), (5, 2, 1), (1, 2, 1)])
 def test_keyswitch_rotation_rescale(gpu, pha, orc, world, size_p, chain_index):
     from phantom_fhe_amd.limb_parallel import LimbParallelEvaluator, limb_window
     mods = orc.coeff_modulus_create(N, [45] * 6 + [55] * size_p)
@@ -148,6 +148,22 @@ def test_torch_distributed_ranks(gpu, backend, nproc):
                           "--p-bits", "55", "--check"], capture_output=True, text=True, timeout=170, env=env)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     assert out.stdout.count("ok rank") == nproc
+
+
+def test_full_size_two_ranks_equal_single_gpu(gpu):
+    """BASELINE configs[2] at full size (N = 2^16, 36 + 12 limbs, dnum 3) on two torch.distributed ranks (gloo, sharing
+    this GPU): the sharded HMult + relinearise and a rotation reproduce pha_multiply_and_relin_inplace /
+    pha_apply_galois_inplace bit for bit, on the owned limbs and after the gather."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29643", os.path.join(root, "tools", "lp_keyswitch.py"),
+                          "--backend", "gloo", "--check-single"], capture_output=True, text=True, timeout=170, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert out.stdout.count("ok rank") == 2
 
 
 @pytest.mark.parametrize("config,steps", [(2, 20), (3, 5), (4, 2)])

@@ -4,7 +4,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node G --master-addr 127.0.0.1 \
         tools/lp_keyswitch.py [--backend nccl] [--log-n 16 --q-limbs 36 --p-limbs 12] [--check] [--steps K]
 
---check compares every rank's owned limbs with the CPU oracle (small sizes only); otherwise it
+--check compares every rank's owned limbs with the CPU oracle (small sizes only), --check-single with the single-GPU
+entry points on the same inputs (any size, e.g. BASELINE configs[2]); otherwise it
 times K key switches (barrier + synchronize on both sides, max over ranks) and rank 0 prints one
 JSON line.  With --backend gloo all ranks may share one GPU (tests on a one-GPU box)."""
 import argparse
@@ -26,6 +27,8 @@ def main():
     ap.add_argument("--q-bits", type=int, default=50)
     ap.add_argument("--p-bits", type=int, default=60)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--check-single", action="store_true",
+                    help="compare HMult + relinearise and a rotation with the single-GPU entry points on the same inputs (any size)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     args = ap.parse_args()
@@ -76,6 +79,34 @@ def main():
         out3 = torch.empty((3, size_ql, n), dtype=torch.int64, device="cuda")
         prod = ev.multiply_and_relin(1, pha.to_device(ct), pha.to_device(ct_b), evk, out3)
         assert (pha.to_host(prod)[:, q0:q0 + qc] == exp_mul[:, q0:q0 + qc]).all(), f"rank {rank}: HMult + relin differs"
+        dist.barrier()
+        print(f"ok rank {rank}/{world} window Q[{q0},+{qc}) P[{p0},+{pc})", flush=True)
+    elif args.check_single:
+        # every rank runs the single-GPU operation on a context of its own and the sharded one on the shared inputs: the
+        # owned limbs, then the gathered ciphertext, must equal pha_multiply_and_relin_inplace / pha_apply_galois_inplace
+        dev = torch.device("cuda")
+        g = torch.Generator(device=dev).manual_seed(11)                # the same inputs on every rank
+        lo = int(mods.min())
+        rnd = lambda *shape: torch.randint(0, lo, shape, dtype=torch.int64, device=dev, generator=g)  # noqa: E731
+        ct_a, ct_b = rnd(2, size_ql, n), rnd(2, size_ql, n)
+        evk = pha.EvalKey([rnd(2, size_qp, n) for _ in range(beta)])
+        single = pha.PhantomContext(args.log_n, mods, args.p_limbs)
+        want = torch.cat([ct_a.clone(), torch.zeros((1, size_ql, n), dtype=torch.int64, device=dev)])
+        single.multiply_and_relin_inplace(1, want, ct_b.clone(), evk)
+        out3 = torch.full((3, size_ql, n), -1, dtype=torch.int64, device=dev)
+        prod = ev.multiply_and_relin(1, ct_a.clone(), ct_b.clone(), evk, out3)
+        torch.cuda.synchronize()
+        assert torch.equal(prod[:, q0:q0 + qc], want[:2, q0:q0 + qc]), f"rank {rank}: HMult + relinearise differs on the owned limbs"
+        ev.gather_limbs(1, [prod[0], prod[1]])
+        assert torch.equal(prod, want[:2]), f"rank {rank}: gathered HMult + relinearise differs"
+        elt = pha.galois_elt_from_step(args.log_n, 5)
+        want_rot = ct_a.clone()
+        single.apply_galois_inplace(1, want_rot, elt, evk)
+        rot = ct_a.clone()
+        ev.apply_galois_inplace(1, rot, elt, evk)
+        torch.cuda.synchronize()
+        assert torch.equal(rot[:, q0:q0 + qc], want_rot[:, q0:q0 + qc]), f"rank {rank}: rotation differs on the owned limbs"
+        single.close()
         dist.barrier()
         print(f"ok rank {rank}/{world} window Q[{q0},+{qc}) P[{p0},+{pc})", flush=True)
     else:

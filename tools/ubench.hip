@@ -1,10 +1,11 @@
 // Micro-benchmarks that decide the NTT design on gfx950: integer multiply issue rates, the cost
 // of one Shoup butterfly, FP64 FMA rate, and in-place streaming bandwidth at cache-resident and
-// HBM-resident footprints.  Build: hipcc -O3 --offload-arch=gfx950 tools/ubench.hip -o tools/ubench
+// HBM-resident footprints; `ubench exchange`: lane-exchange primitives against the LDS exchange.  Build: hipcc -O3 --offload-arch=gfx950 tools/ubench.hip -o tools/ubench
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
@@ -89,7 +90,144 @@ int run_alu(const char *name, uint64_t *d_out, double ops_per_iter) {
     return 0;
 }
 
+// ---- exchange of the 16 values a lane holds with the other lanes (mode "exchange") ----------------------------------
+// What a radix-16 register pass needs between two passes: a transpose between the register index and four bits of
+// the thread index.  Every variant moves all 16 64-bit values of every lane once per iteration; a little FP64 work
+// between iterations keeps the values live.  X_LDS / X_LDS_BARRIER: ds_write_b64 x16, (workgroup barrier), ds_read_b64
+// x16 -- the shipped exchange (the barrier variant is what a cross-wave transpose costs).  X_SWAP32 / X_SWAP16: one
+// butterfly level at lane distance 32 / 16 with v_permlane32_swap / v_permlane16_swap (16 instructions).  X_DPP8: one
+// level at distance 8 with v_mov_dpp row_ror:8 and selects.  X_DPP_ROW: the full 16 x 16 transpose inside a 16-lane row,
+// four levels (8, 4, 2, 1; distances below 8 have no xor form on gfx950: two shifted moves and a select each).
+// X_BPERMUTE: the same transpose through ds_bpermute_b32 (the LDS crossbar without memory), 32 of them.
+enum { X_LDS, X_LDS_BARRIER, X_SWAP32, X_SWAP16, X_DPP8, X_DPP_ROW, X_BPERMUTE, X_NONE };
+typedef unsigned xv2u __attribute__((ext_vector_type(2)));
+
+template <int DIST>
+__device__ __forceinline__ unsigned dpp_xor(unsigned v, bool upper) {
+    // the value of lane (l ^ DIST) within a 16-lane row
+    if (DIST == 8) return __builtin_amdgcn_update_dpp(0u, v, 0x128, 0xf, 0xf, false);   // row_ror:8
+    const unsigned dn = __builtin_amdgcn_update_dpp(0u, v, 0x100 + DIST, 0xf, 0xf, false);   // row_shl: lane l reads l + DIST
+    const unsigned up = __builtin_amdgcn_update_dpp(0u, v, 0x110 + DIST, 0xf, 0xf, false);   // row_shr: lane l reads l - DIST
+    return upper ? up : dn;
+}
+
+template <int DIST>
+__device__ __forceinline__ void dpp_level(double (&r)[16], unsigned lane) {
+    const bool upper = (lane & DIST) != 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (i & DIST) continue;
+        // lanes with the bit clear keep r[i] and send r[i + DIST]; the others keep r[i + DIST] and send r[i]
+        const uint64_t send = __double_as_longlong(upper ? r[i] : r[i + DIST]);
+        const unsigned lo = dpp_xor<DIST>(static_cast<unsigned>(send), upper), hi = dpp_xor<DIST>(static_cast<unsigned>(send >> 32), upper);
+        const double got = __longlong_as_double((static_cast<uint64_t>(hi) << 32) | lo);
+        if (upper) r[i] = got; else r[i + DIST] = got;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void exchange_kernel(double *out, int iters, double seed) {
+    __shared__ double lds[256 * 17];
+    const unsigned tid = threadIdx.x, lane = tid & 63, row = tid >> 4, c = tid & 15;
+    double r[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) r[i] = seed + tid * 16 + i;
+    for (int it = 0; it < iters; it++) {
+        if (MODE == X_LDS || MODE == X_LDS_BARRIER) {
+            // 16 x 16 transpose inside each 16-lane row: lane c writes its register i to [row][c][i], reads [row][i][c]
+#pragma unroll
+            for (int i = 0; i < 16; i++) lds[(row * 16 + c) * 17 + i] = r[i];
+            if (MODE == X_LDS_BARRIER) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 16; i++) r[i] = lds[(row * 16 + i) * 17 + c];
+            if (MODE == X_LDS_BARRIER) __syncthreads();
+        } else if (MODE == X_SWAP32 || MODE == X_SWAP16) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint64_t a = __double_as_longlong(r[i]), b = __double_as_longlong(r[i + 8]);
+                xv2u lo, hi;
+                if (MODE == X_SWAP32) {
+                    lo = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(a), static_cast<unsigned>(b), false, false);
+                    hi = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(a >> 32), static_cast<unsigned>(b >> 32), false, false);
+                } else {
+                    lo = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(a), static_cast<unsigned>(b), false, false);
+                    hi = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(a >> 32), static_cast<unsigned>(b >> 32), false, false);
+                }
+                r[i] = __longlong_as_double((static_cast<uint64_t>(hi.x) << 32) | lo.x);
+                r[i + 8] = __longlong_as_double((static_cast<uint64_t>(hi.y) << 32) | lo.y);
+            }
+        } else if (MODE == X_DPP8) {
+            dpp_level<8>(r, lane);
+        } else if (MODE == X_DPP_ROW) {
+            dpp_level<8>(r, lane);
+            dpp_level<4>(r, lane);
+            dpp_level<2>(r, lane);
+            dpp_level<1>(r, lane);
+        } else if (MODE == X_BPERMUTE) {
+            // register i of lane c <- register c of lane i (same row): rotate the register index by the lane, pull, rotate back
+            double t[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                // step i: lane c pulls from lane (c ^ i) that lane's register (c ^ i) ^ i ... a select chain stands in for the
+                // dynamic register index: the cost measured is the 32 ds_bpermute_b32, as in a real implementation
+                const unsigned src = ((lane & 48) | (c ^ i)) << 2;
+                const uint64_t v = __double_as_longlong(r[i]);
+                const unsigned lo = __builtin_amdgcn_ds_bpermute(src, static_cast<unsigned>(v));
+                const unsigned hi = __builtin_amdgcn_ds_bpermute(src, static_cast<unsigned>(v >> 32));
+                t[i] = __longlong_as_double((static_cast<uint64_t>(hi) << 32) | lo);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) r[i] = t[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) r[i] = __builtin_fma(r[i], 1.0000001, 0.25);   // 16 FP64 FMAs: one butterfly column's worth
+    }
+    double acc = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc += r[i];
+    out[blockIdx.x * 256 + tid] = acc;
+}
+
+template <int MODE>
+static double time_exchange(const char *name, double *d_out, double base_ns) {
+    const int iters = 2000, grid = 256 * 8;   // 8 workgroups = 32 waves per CU: 8 per SIMD
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(exchange_kernel<MODE>, dim3(grid), dim3(256), 0, 0, d_out, iters, 1.5);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(exchange_kernel<MODE>, dim3(grid), dim3(256), 0, 0, d_out, iters, 1.5);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    // per SIMD: 8 waves share it, each doing `iters` exchanges
+    const double ns_per_exchange = 1e6 * ms / iters / 8.0;
+    printf("%-44s %8.1f ns per exchange and wave (SIMD time)   %8.1f ns over the FMA-only loop\n", name, ns_per_exchange,
+           ns_per_exchange - base_ns);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return ns_per_exchange;
+}
+
+static int exchange_mode() {
+    double *d_out;
+    CHECK(hipMalloc(&d_out, 256 * 8 * 256 * sizeof(double)));
+    printf("16 x 64-bit values per lane, 8 waves per SIMD, 16 FP64 FMAs between exchanges\n");
+    const double base = time_exchange<X_NONE>("no exchange (16 FMAs only)", d_out, 0.0);
+    time_exchange<X_LDS>("LDS, intra-row transpose, no barrier", d_out, base);
+    time_exchange<X_LDS_BARRIER>("LDS, two workgroup barriers (shipped form)", d_out, base);
+    time_exchange<X_SWAP32>("v_permlane32_swap, one level (distance 32)", d_out, base);
+    time_exchange<X_SWAP16>("v_permlane16_swap, one level (distance 16)", d_out, base);
+    time_exchange<X_DPP8>("DPP row_ror:8 + selects, one level", d_out, base);
+    time_exchange<X_DPP_ROW>("DPP, full 16x16 row transpose (4 levels)", d_out, base);
+    time_exchange<X_BPERMUTE>("ds_bpermute_b32 x32, full row transpose", d_out, base);
+    CHECK(hipDeviceSynchronize());
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && std::string(argv[1]) == "exchange") return exchange_mode();
     if (argc > 1) {
         // calibration mode for the FETCH_SIZE / WRITE_SIZE counters: known byte counts
         // (512 MiB read + 512 MiB written per launch), 3 launches of each access width
