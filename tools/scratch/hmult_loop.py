@@ -21,6 +21,8 @@ for _ in range(reps):
 e1.record()
 e1.synchronize()
 print(f"PHA_KS_OVERLAP={os.environ.get('PHA_KS_OVERLAP', '1')}: HMult + relin {1e3 * e0.elapsed_time(e1) / reps:.1f} us", flush=True)
+if os.environ.get("ONLY_HMULT"):
+    sys.exit(0)
 elt = pha.galois_elt_from_step(16, 1)
 ct = rnd(2, size_q)
 e0.record()
