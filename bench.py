@@ -74,7 +74,7 @@ def parse(argv=None):
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4))
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: CPU-side rehearsal of the launcher path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the HMult/rotate/bootstrap side measurements")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the HMult/rotate/bootstrap side measurements and roofline.int_path (profiling runs: kernel statistics then hold the headline chain only)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal without a GPU: the ranks rendezvous, time an empty step and print the line")
     ap.add_argument("--pmc-traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
@@ -433,6 +433,8 @@ def roofline_config2(torch, ctx, buf, orig, mods, args):
     }
     if note:
         roof["traffic_note"] = note
+    if args.no_secondary:   # profiling runs (tools/profile.sh): the kernel statistics must hold the headline chain's launches only
+        return roof
     # the same transform with every limb on the integer butterflies (the reference's grids are 55/60-bit chains,
     # tests/relin.cu:98-130, and q0 + the special primes of configs[2] are 60-bit)
     import phantom_fhe_amd as pha
