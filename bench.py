@@ -412,6 +412,8 @@ def roofline_config2(torch, ctx, buf, orig, mods, args):
             tj = json.load(f)
         if tj.get("source_hash") == kernel_source_hash():
             traffic = tj["fwd_col"] + tj["fwd_row"]
+            note = (f"bytes per forward transform from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of these kernel "
+                    f"sources ({os.path.basename(args.pmc_traffic_json)}, tag {tj.get('tag')}, tools/profile.sh), not counted in this run")
         else:
             note = "profiles/traffic_latest.json was measured on other kernel sources (source_hash differs): not reported"
     except Exception as e:  # noqa: BLE001

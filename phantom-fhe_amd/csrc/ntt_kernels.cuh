@@ -244,6 +244,26 @@ struct CanonTw {
     __device__ __forceinline__ TW operator()(int s, int jb) const { return tw[(node << s) + jb]; }
 };
 
+// twiddles of a radix-2^R block already in registers (slot (1 << s) - 1 + jb), fetched ahead of the barrier in front of
+// the block so that their latency is not paid stage by stage behind it
+template <int R, class TW>
+struct PreTw {
+    TW w[(1 << R) - 1];
+    __device__ __forceinline__ TW operator()(int s, int jb) const { return w[(1 << s) - 1 + jb]; }
+};
+template <int R, class TW>
+__device__ __forceinline__ PreTw<R, TW> prefetch_tw(const TW *tw, uint32_t node) {
+    PreTw<R, TW> r;
+#pragma unroll
+    for (int s = 0; s < R; s++)
+#pragma unroll
+        for (int jb = 0; jb < (1 << s); jb++) r.w[(1 << s) - 1 + jb] = tw[(node << s) + jb];
+    return r;
+}
+#ifndef PHA_TW_PREFETCH
+#define PHA_TW_PREFETCH 1
+#endif
+
 template <int RB, class TW>
 struct LastPassTw {
     const TW *base;  // already offset to (chunk, lane)
@@ -411,6 +431,10 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, const uint64_t (&ra
         for (int j = 0; j < (1 << RA); j++) lds[lds_col<C, RB>((j << RB) | r_lo, c)] = F::raw(x[j]);
     }
     PHA_TRACE_MARK(1);
+    // one group per lane and 8-byte twiddles: the second pass's 2^RB - 1 twiddles are requested before the barrier
+    constexpr bool kPre = PHA_TW_PREFETCH && GB == 1 && sizeof(TW) == 8;
+    PreTw<kPre ? RB : 1, TW> pre;
+    if constexpr (kPre) pre = prefetch_tw<RB, TW>(tw, (root << RA) + t / C);
     __syncthreads();
     PHA_TRACE_MARK(2);
 #pragma unroll
@@ -419,7 +443,10 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, const uint64_t (&ra
         typename F::elem x[1 << RB];
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(lds[lds_col<C, RB>((r_hi << RB) | j, c)]);
-        ct_radix<RB, RA>(x, CanonTw<TW>{tw, (root << RA) + r_hi}, f);
+        if constexpr (kPre)
+            ct_radix<RB, RA>(x, pre, f);
+        else
+            ct_radix<RB, RA>(x, CanonTw<TW>{tw, (root << RA) + r_hi}, f);
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) {
             uint64_t *p = &base[static_cast<size_t>((r_hi << RB) | j) * n2 + c];
@@ -659,6 +686,9 @@ __device__ __forceinline__ void intt_row_body(uint64_t *lds, const uint64_t (&ra
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) lds[lds_row(e0 + j)] = F::raw(x[j]);
     }
+    constexpr bool kPre = PHA_TW_PREFETCH && GC == 1 && sizeof(TW) == 8;
+    PreTw<kPre ? RA : 1, TW> pre;
+    if constexpr (kPre) pre = prefetch_tw<RA, TW>(tw, n1 + ti * RW + (t >> RB));
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < GC; g++) {
@@ -666,7 +696,10 @@ __device__ __forceinline__ void intt_row_body(uint64_t *lds, const uint64_t (&ra
         typename F::elem x[1 << RA];
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) x[j] = F::unraw(lds[lds_row(a * L + ((j << RB) | b_lo))]);
-        gs_radix<RA, false>(x, CanonTw<TW>{tw, n1 + ti * RW + a}, f, unused);
+        if constexpr (kPre)
+            gs_radix<RA, false>(x, pre, f, unused);
+        else
+            gs_radix<RA, false>(x, CanonTw<TW>{tw, n1 + ti * RW + a}, f, unused);
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) st_stream(&dst[a * L + ((j << RB) | b_lo)], F::raw(x[j]));
     }
