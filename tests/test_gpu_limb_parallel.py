@@ -130,6 +130,18 @@ def test_window_validation(gpu, pha, orc):
     assert e.value.code == pha.PHA_ERR_INVALID_ARGUMENT
     with pytest.raises(pha.PhantomError):
         ctx.lp_moddown_begin(1, d, d, (0, 0, 1, 2))  # P window [1,3) exceeds alpha = 2
+    # exchange buffers: rows beyond the buffer and row tables pointing outside it are refused, nothing is launched
+    c2 = pha.to_device(np.zeros((4, N), dtype=np.uint64))
+    small = pha.to_device(np.zeros((3, N), dtype=np.uint64))
+    t_mod_up = pha.to_device(np.zeros((2, 6, N), dtype=np.uint64))
+    for call in (lambda: ctx.lp_modup_begin(1, c2, small, (0, 2, 0, 0), row_begin=2),            # rows 2, 3 of a 3-row buffer
+                 lambda: ctx.lp_modup_finish(1, t_mod_up, c2, small, (0, 2, 0, 1)),              # fewer rows than Q_l has limbs
+                 lambda: ctx.lp_modup_finish(1, t_mod_up, c2, c2, (0, 2, 0, 1), q_rows=[0, 1, 2, 4]),
+                 lambda: ctx.lp_moddown_begin(1, d, small, (0, 0, 0, 2), row_begin=0, poly_stride=2),   # poly 1 needs rows 2, 3
+                 lambda: ctx.lp_moddown_finish(1, d, d, small, (0, 2, 0, 0), p_rows=[0, 1], poly_stride=2)):
+        with pytest.raises(pha.PhantomError) as e:
+            call()
+        assert e.value.code == pha.PHA_ERR_INVALID_ARGUMENT
     ctx.close()
 
 
