@@ -148,3 +148,15 @@ def test_cpp_host_layer_against_oracle(gpu, orc):
     # public-key encryption: decrypts to the message, two encryptions of one plaintext differ.  Scale 2^30; the
     # division by P is the reference's uncentred moddown, whose +1/2 mean per coefficient lands on slot 0 (9e-5)
     assert res["asymmetric_err"] < 1e-3 and res["asymmetric_fresh_randomness"] > 0.99 and res["asymmetric_limbs"] == 4
+
+
+@pytest.mark.gpu
+def test_cpp_limb_parallel_host_layer(gpu):
+    """phantom-fhe_amd/host/limb_parallel.hpp (the RCCL twin of limb_parallel.py): HMult + relinearise, rotation and rescale
+    through LocalComm and through a one-rank RCCL communicator equal the single-GPU entry points bit for bit."""
+    binary = os.path.join(os.path.dirname(__file__), "cpp", "lp_test")
+    assert os.path.exists(binary), "tests/cpp/lp_test not built (run __graft_entry__.build())"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([binary], capture_output=True, text=True, timeout=170, env=env)
+    assert out.returncode == 0 and "lp_test ok" in out.stdout, out.stdout + out.stderr[-2000:]
+    assert "local: rank 0 of 1" in out.stdout and "rccl: rank 0 of 1" in out.stdout
