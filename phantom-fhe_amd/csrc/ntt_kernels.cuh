@@ -485,6 +485,90 @@ __global__ PHA_NTT_BOUNDS void fntt_col_kernel(uint64_t *data, size_t poly_strid
         fntt_col_body<S1, RA>(lds, raw, base, tw, st.n2, st.root, IntField<NARROW>(mod));
 }
 
+// Experiment (PHA_COL8=1 at context creation; profiles/EXPERIMENTS.md 3.9): the same column tile with EIGHT
+// coefficients per lane -- 512 threads, three register passes of 3 + 3 + 2 stages, two LDS exchanges -- so that a
+// lane needs 64-76 VGPRs and a SIMD holds six to eight waves instead of four.  After the first exchange a wave owns
+// 32 consecutive rows of the tile, which the remaining five stages never leave: the second exchange is wave-local.
+// Stage for stage the butterflies are those of fntt_col_kernel<8, 4>, so the raw output is bit-identical.
+// Measured at 72 limbs of N = 2^16 (profiles/r3o_col8_ab.log): FP64 limbs 16.2-16.3 us against 16.4-16.5 us, 60-bit
+// limbs 20.5 us (six waves, no spills) or 22.6 us (eight waves, 4-6 spilled VGPRs) against 22.0 us; the headline and
+// HMult do not move.  Twice the waves on the same four workgroups per CU buy nothing: the pass is not latency-bound.
+#ifndef PHA_COL8_WAVES
+#define PHA_COL8_WAVES 6
+#endif
+constexpr int kThreads8 = kTile / 8;
+__device__ __forceinline__ uint32_t lds_col8(uint32_t r, uint32_t c) {
+    return r * 16 + c + (r >> 3) * 16;   // rows 8 apart (the third pass's quarter-waves) fall into different bank halves
+}
+template <class F>
+__device__ __forceinline__ void fntt_col8_body(uint64_t *lds, const uint64_t (&raw)[8], uint64_t *base, const tw_t *tw_raw,
+                                               uint32_t n2, uint32_t root, const F &f) {
+    using TW = typename F::twl;
+    const TW *tw = reinterpret_cast<const TW *>(tw_raw);
+    const uint32_t t = pha_tid(), c = t & 15u;
+    typename F::elem x[8];
+    {
+        const uint32_t r_lo = t >> 4;
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = f.from_u64(raw[j]);
+        ct_radix<3, 0>(x, CanonTw<TW>{tw, root}, f);
+#pragma unroll
+        for (int j = 0; j < 8; j++) lds[lds_col8((j << 5) | r_lo, c)] = F::raw(x[j]);
+    }
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(t >> 6), q = (t >> 4) & 3u;
+    __syncthreads();
+    {
+        const uint32_t r0 = (wave << 5) | q;
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = F::unraw(lds[lds_col8(r0 + (j << 2), c)]);
+        ct_radix<3, 3>(x, CanonTw<TW>{tw, (root << 3) + wave}, f);
+#pragma unroll
+        for (int j = 0; j < 8; j++) lds[lds_col8(r0 + (j << 2), c)] = F::raw(x[j]);
+    }
+    // rows [32 wave, 32 wave + 32) belong to this wave alone from here on: its own LDS operations complete in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        const uint32_t r0 = (wave << 5) | (q << 3);
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = F::unraw(lds[lds_col8(r0 + j, c)]);
+        typename F::elem lo[4] = {x[0], x[1], x[2], x[3]}, hi[4] = {x[4], x[5], x[6], x[7]};
+        const uint32_t node = (root << 6) + (r0 >> 2);
+        ct_radix<2, 6>(lo, CanonTw<TW>{tw, node}, f);
+        ct_radix<2, 6>(hi, CanonTw<TW>{tw, node + 1}, f);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            st_stream(&base[static_cast<size_t>(r0 + j) * n2 + c], F::raw(lo[j]));
+            st_stream(&base[static_cast<size_t>(r0 + 4 + j) * n2 + c], F::raw(hi[j]));
+        }
+    }
+}
+template <bool NARROW>
+__global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(PHA_COL8_WAVES, 8))) void fntt_col8_kernel(
+    uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm) {
+    __shared__ uint64_t lds[kTile + 512];
+    const uint32_t n = 1u << T.log_n, tiles = n >> kTileLog;
+    BlockWork bw;
+    if (!decode_block(blockIdx.x, lm, tiles, bw)) return;
+    uint32_t twr, tidx;
+    if (!resolve_limb(lm, bw.poly, bw.li, twr, tidx)) return;
+    const SubTree st = sub_tree<8>(T, bw.ti);
+    uint64_t *base = data + bw.poly * poly_stride + static_cast<size_t>(twr) * n + st.offset + st.tile * 16;
+    uint64_t raw[8];
+    {
+        const uint32_t t = pha_tid(), c = t & 15u, r_lo = t >> 4;
+#pragma unroll
+        for (int j = 0; j < 8; j++) raw[j] = base[static_cast<size_t>((j << 5) | r_lo) * st.n2 + c];
+    }
+    const DModulus mod = T.mod[tidx];
+    const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
+    if (use_fp64(T, mod))
+        fntt_col8_body(lds, raw, base, tw, st.n2, st.root, FpField(mod));
+    else
+        fntt_col8_body(lds, raw, base, tw, st.n2, st.root, IntField<NARROW>(mod));
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward, row phase: stages m = 2^S1 .. N/2, final reduction to [0,q), optional fused epilogue
 // ---------------------------------------------------------------------------------------------

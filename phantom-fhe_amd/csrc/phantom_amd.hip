@@ -188,6 +188,7 @@ struct pha_context {
     DevBuf<DModulus> d_mod;
     DevBuf<tw_t> d_tw, d_itw, d_twD, d_itwD;
     DevBuf<double> d_twG, d_itwG;     // generators of the last pass's twiddles (FP64 limbs; numth.hpp build_generator_table)
+    bool col8 = false;                // PHA_COL8=1: forward column pass with eight coefficients per lane (experiment)
     bool gen_tw = false;              // the row passes derive their last-pass twiddles (PHA_GEN_TW=0: read them from twD)
     DevBuf<uint64_t> d_n_inv, d_n_inv_shoup;
     uint32_t twD_stride = 0;
@@ -395,6 +396,10 @@ int upload_tables(pha_context *ctx) {
         const char *e = getenv("PHA_GEN_TW");
         ctx->gen_tw = !(e && e[0] == '0');
     }
+    {
+        const char *c8 = getenv("PHA_COL8");
+        ctx->col8 = c8 && c8[0] == '1' && kTileLog == 12;
+    }
     HIP_TRY(ctx->d_mod.upload(mods));
     HIP_TRY(ctx->d_n_inv.upload(ninv));
     HIP_TRY(ctx->d_n_inv_shoup.upload(ninv_s));
@@ -548,7 +553,12 @@ int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stri
     if ((phases & 1) && T.split)
         hipLaunchKernelGGL(split_fwd_kernel, dim3(ntt_grid_blocks(xcd, r.active, polys, ctx->n >> 13)), dim3(256), 0, st,
                            data, poly_stride, T, rr.lm);
-    if (phases & 1)
+    if ((phases & 1) && ctx->col8 && ctx->plan.s1 == 8) {
+        if (ctx->narrow)
+            hipLaunchKernelGGL(fntt_col8_kernel<true>, grid, dim3(kThreads8), 0, st, data, poly_stride, T, rr.lm);
+        else
+            hipLaunchKernelGGL(fntt_col8_kernel<false>, grid, dim3(kThreads8), 0, st, data, poly_stride, T, rr.lm);
+    } else if (phases & 1)
     DISPATCH_S(ctx->plan.s1, 0, (launch_fcol<6, 3>(ctx->narrow, grid, st, data, poly_stride, T, rr.lm)),
                (launch_fcol<7, 4>(ctx->narrow, grid, st, data, poly_stride, T, rr.lm)),
                (launch_fcol<8, 4>(ctx->narrow, grid, st, data, poly_stride, T, rr.lm)));

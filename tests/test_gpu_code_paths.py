@@ -134,3 +134,27 @@ def test_derived_twiddles_equal_table_twiddles(gpu, pha, log_n):
     assert gpu.equal(a, b) and gpu.equal(a, x), "inverse transform differs"
     derived.close()
     table.close()
+
+
+@pytest.mark.parametrize("log_n,bits", [(16, [60] * 3 + [50] * 5), (17, [60] * 2 + [50] * 2), (15, [60, 50, 45])])
+def test_eight_per_lane_column_pass_equals_default(gpu, pha, log_n, bits):
+    """PHA_COL8=1 (csrc/ntt_kernels.cuh fntt_col8_kernel; applies where the column pass has eight stages, a no-op at
+    N = 2^15) stores the same words as the default forward transform, on FP64 and on integer limbs."""
+    n = 1 << log_n
+    mods = pha.coeff_modulus_create(n, bits)
+    col8 = _ctx(pha, log_n, mods, 0, PHA_COL8=1)
+    base = _ctx(pha, log_n, mods, 0, PHA_COL8=0)
+    x = _uniform(gpu, mods, mods, n, 11)
+    a, b = x.clone(), x.clone()
+    col8.nwt_2d_radix8_forward_inplace(a, len(mods), 0)
+    base.nwt_2d_radix8_forward_inplace(b, len(mods), 0)
+    assert gpu.equal(a, b), "forward transform differs"
+    a2, b2 = gpu.stack([x, a]), gpu.stack([x, a])                 # batched launch: two polys
+    col8.ntt_forward_batched(a2, 2, len(mods), len(mods), 0)
+    base.ntt_forward_batched(b2, 2, len(mods), len(mods), 0)
+    assert gpu.equal(a2, b2) and gpu.equal(a2[0], a)
+    col8.nwt_2d_radix8_backward_inplace(a, len(mods), 0)
+    gpu.cuda.synchronize()
+    assert gpu.equal(a, x)
+    col8.close()
+    base.close()
