@@ -72,6 +72,61 @@ __global__ __launch_bounds__(256) void stream_rw8_kernel(uint64_t *buf, size_t n
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n8; i += gridDim.x * 256ull) buf[i] += 1;
 }
 
+// read R 16-B words and write W 16-B words per step: the read : write mixes of the streaming kernels (mode "mix")
+template <int R, int W>
+__global__ __launch_bounds__(256) void stream_mix_kernel(const ulonglong2 *src, ulonglong2 *dst, size_t steps) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < steps; i += gridDim.x * 256ull) {
+        ulonglong2 acc = {i, 3};
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const ulonglong2 v = src[r * steps + i];
+            acc.x += v.x;
+            acc.y ^= v.y;
+        }
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            acc.x += w;
+            dst[w * steps + i] = acc;
+        }
+    }
+}
+template <int R, int W>
+int run_mix(const ulonglong2 *src, ulonglong2 *dst, size_t steps, int grid) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int reps = 50;
+    for (int r = 0; r < 3; r++) hipLaunchKernelGGL((stream_mix_kernel<R, W>), dim3(grid), dim3(256), 0, 0, src, dst, steps);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL((stream_mix_kernel<R, W>), dim3(grid), dim3(256), 0, 0, src, dst, steps);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double bytes = 16.0 * steps * (R + W);
+    printf("read %d : write %d, %6.1f MiB read + %6.1f MiB written, grid %5d: %7.2f us/launch  %6.2f TB/s\n", R, W,
+           16.0 * steps * R / 1048576.0, 16.0 * steps * W / 1048576.0, grid, 1e3 * ms / reps, bytes * reps / (ms * 1e-3) / 1e12);
+    return 0;
+}
+int mix_mode() {
+    // 18 MiB units: read 1 : write 3 is the modup's conversion at configs[2] (18 MiB in, 54 MiB out), 1 : 3 at 12 MiB its
+    // moddown (12 in, 36 out); 4 : 3 the tensor product; 1 : 0 and 0 : 1 the pure directions
+    void *src, *dst;
+    CHECK(hipMalloc(&src, 128ull << 20)); CHECK(hipMalloc(&dst, 128ull << 20));
+    CHECK(hipMemset(src, 1, 128ull << 20)); CHECK(hipMemset(dst, 1, 128ull << 20));
+    const ulonglong2 *s = (const ulonglong2 *)src; ulonglong2 *d = (ulonglong2 *)dst;
+    for (int grid : {1024, 2048, 4096}) {
+        const size_t u18 = (18ull << 20) / 16, u12 = (12ull << 20) / 16;
+        run_mix<1, 0>(s, d, 4 * u18, grid);
+        run_mix<0, 1>(s, d, 4 * u18, grid);
+        run_mix<0, 3>(s, d, u18, grid);
+        run_mix<1, 3>(s, d, u18, grid);
+        run_mix<1, 3>(s, d, u12, grid);
+        run_mix<4, 3>(s, d, u18, grid);
+        run_mix<1, 1>(s, d, 2 * u18, grid);
+    }
+    return 0;
+}
+
 template <int OP>
 int run_alu(const char *name, uint64_t *d_out, double ops_per_iter) {
     const int blocks = 256 * 8;
@@ -228,6 +283,7 @@ static int exchange_mode() {
 
 int main(int argc, char **argv) {
     if (argc > 1 && std::string(argv[1]) == "exchange") return exchange_mode();
+    if (argc > 1 && std::string(argv[1]) == "mix") return mix_mode();
     if (argc > 1) {
         // calibration mode for the FETCH_SIZE / WRITE_SIZE counters: known byte counts
         // (512 MiB read + 512 MiB written per launch), 3 launches of each access width
