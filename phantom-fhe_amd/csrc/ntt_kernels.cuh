@@ -155,6 +155,24 @@ __device__ unsigned long long *pha_trace_buf;
 #else
 #define PHA_TRACE_MARK(slot)
 #endif
+// -DPHA_TRACE=3 (tools/scratch/trace2.py): two timestamps per workgroup only -- entry, before the loads are issued, and
+// exit, after the stores are issued -- written by thread 0 at the exit.  The five phase marks above cost a workgroup
+// 2-3 us of its life (each waits for its clock read); this form changes the kernel time by less than 1 us.
+#if defined(PHA_TRACE) && PHA_TRACE == 3
+#undef PHA_TRACE_MARK
+#define PHA_TRACE_MARK(slot)
+#define PHA_TRACE_ENTRY() const unsigned long long pha_trace_t0 = wall_clock64()
+#define PHA_TRACE_EXIT()                                                 \
+    do {                                                                 \
+        if (threadIdx.x == 0 && pha_trace_buf) {                         \
+            pha_trace_buf[blockIdx.x * 8] = pha_trace_t0;                \
+            pha_trace_buf[blockIdx.x * 8 + 4] = wall_clock64();          \
+        }                                                                \
+    } while (0)
+#else
+#define PHA_TRACE_ENTRY()
+#define PHA_TRACE_EXIT()
+#endif
 
 // returns false when this workgroup has nothing to do (ragged last digit)
 __device__ __forceinline__ bool resolve_limb(const LimbMap &m, uint32_t poly, uint32_t li, uint32_t &twr, uint32_t &tidx) {
@@ -457,8 +475,8 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, const uint64_t (&ra
         }
     }
     PHA_TRACE_MARK(3);
-#ifdef PHA_TRACE
-    __builtin_amdgcn_s_waitcnt(0);      // stores acknowledged
+#if defined(PHA_TRACE) && PHA_TRACE != 3
+    __builtin_amdgcn_s_waitcnt(0);      // stores acknowledged (keeps the workgroup until they are)
     PHA_TRACE_MARK(4);
 #endif
 }
@@ -468,6 +486,7 @@ __global__ PHA_NTT_BOUNDS void fntt_col_kernel(uint64_t *data, size_t poly_strid
     constexpr int C = kTile >> S1;
     __shared__ uint64_t lds[kLdsWords];
     const uint32_t n = 1u << T.log_n, tiles = n >> kTileLog;
+    PHA_TRACE_ENTRY();
     BlockWork bw;
     if (!decode_block(blockIdx.x, lm, tiles, bw)) return;
     const uint32_t poly = bw.poly, ti = bw.ti;
@@ -483,6 +502,7 @@ __global__ PHA_NTT_BOUNDS void fntt_col_kernel(uint64_t *data, size_t poly_strid
         fntt_col_body<S1, RA>(lds, raw, base, tw, st.n2, st.root, FpField(mod));
     else
         fntt_col_body<S1, RA>(lds, raw, base, tw, st.n2, st.root, IntField<NARROW>(mod));
+    PHA_TRACE_EXIT();
 }
 
 // Experiment (PHA_COL8=1 at context creation; profiles/EXPERIMENTS.md 3.9): the same column tile with EIGHT

@@ -34,7 +34,8 @@ def main():
     for log_n, bits in cases:
         n = 1 << log_n
         mods = pha.coeff_modulus_create(n, bits)
-        base, col8 = ctx_with(log_n, mods, PHA_COL8=0), ctx_with(log_n, mods, PHA_COL8=1)
+        key, val = (sys.argv[3].split("=") if len(sys.argv) > 3 else ("PHA_COL8", "1"))
+        base, col8 = ctx_with(log_n, mods, **{key: 0}), ctx_with(log_n, mods, **{key: val})
         x = uniform(mods, n, 2, log_n)
         a, b = x.clone(), x.clone()
         for p in range(2):
@@ -43,17 +44,19 @@ def main():
         torch.cuda.synchronize()
         print(f"log_n {log_n} limbs {len(mods)} bits {bits[-1]}: equal = {bool(torch.equal(a, b))}", flush=True)
         if log_n == 16:
-            for name, ctx in (("default", base), ("col8", col8), ("default", base), ("col8", col8)):
+            phase = int(os.environ.get("AB_PHASE", "0"))
+            inverse = bool(int(os.environ.get("AB_INVERSE", "0")))
+            for name, ctx in (("default", base), ("variant", col8), ("default", base), ("variant", col8)):
                 y = x.clone()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 for _ in range(5):
-                    ctx.ntt_launch_phase(y, 2, len(mods), len(mods), 0, False, 0)
+                    ctx.ntt_launch_phase(y, 2, len(mods), len(mods), 0, inverse, phase)
                 e0.record()
                 for _ in range(iters):
-                    ctx.ntt_launch_phase(y, 2, len(mods), len(mods), 0, False, 0)    # column kernel only, 72 limbs
+                    ctx.ntt_launch_phase(y, 2, len(mods), len(mods), 0, inverse, phase)    # column kernel only, 72 limbs
                 e1.record()
                 torch.cuda.synchronize()
-                print(f"  {name:8s} {e0.elapsed_time(e1) / iters * 1e3:8.2f} us per 72-limb column pass", flush=True)
+                print(f"  {name:8s} {e0.elapsed_time(e1) / iters * 1e3:8.2f} us per 72-limb pass (phase {phase}, inverse {inverse})", flush=True)
         base.close()
         col8.close()
 
