@@ -51,18 +51,17 @@ def _uniform_evk(o, seed):
                       o.uniform_poly(list(range(o.size_QP)), seed + 2 * d + 1)]) for d in range(beta_max)]
 
 
-@pytest.mark.parametrize("world,size_p,chain_index", [(2, 2, 1), (3, 2, 2), (8, 2, 1), (4, 1, 1), (3, 3, 1), (2, 3, 3),
-                                                      (5, 1, 4), (4, 3, 2), (5, 2, 1), (1, 2, 1)])
-def test_keyswitch_rotation_rescale(gpu, pha, orc, world, size_p, chain_index):
+def _check_world(gpu, pha, orc, log_n, mods, size_p, chain_index, world):
+    """every limb-parallel operation on `world` simulated ranks against the oracle's single-device result"""
     from phantom_fhe_amd.limb_parallel import LimbParallelEvaluator, limb_window
-    mods = orc.coeff_modulus_create(N, [45] * 6 + [55] * size_p)
-    o = orc.Oracle(LOG_N, mods, size_p)
+    n = 1 << log_n
+    o = orc.Oracle(log_n, mods, size_p)
     size_ql = o.size_Q - (chain_index - 1)
     lim = list(range(size_ql))
     ct = np.stack([o.uniform_poly(lim, 31), o.uniform_poly(lim, 32)])
     c2 = o.uniform_poly(lim, 33)
     evk_h = _uniform_evk(o, 200)
-    elt = orc.galois_elt_from_step(LOG_N, 3)
+    elt = orc.galois_elt_from_step(log_n, 3)
 
     exp_ks = ct.copy()
     o.keyswitch_inplace(size_ql, exp_ks, c2, evk_h)
@@ -81,7 +80,7 @@ def test_keyswitch_rotation_rescale(gpu, pha, orc, world, size_p, chain_index):
     assert sorted(l for _, _, p0, pc in wins for l in range(p0, p0 + pc)) == list(range(size_p))
 
     def body(rank, comm):
-        ctx = pha.PhantomContext(LOG_N, mods, size_p)
+        ctx = pha.PhantomContext(log_n, mods, size_p)
         ev = LimbParallelEvaluator(ctx, comm)
         q0, qc, _, _ = ev.windows(chain_index)[rank]
         evk = pha.EvalKey([pha.to_device(k) for k in evk_h])
@@ -92,7 +91,7 @@ def test_keyswitch_rotation_rescale(gpu, pha, orc, world, size_p, chain_index):
         ev.gather_limbs(chain_index, [d_ct[0], d_ct[1]])
         out["ks_full"] = pha.to_host(d_ct)
 
-        d_out3 = pha.to_device(np.full((3, size_ql, N), POISON, dtype=np.uint64))
+        d_out3 = pha.to_device(np.full((3, size_ql, n), POISON, dtype=np.uint64))
         prod = ev.multiply_and_relin(chain_index, pha.to_device(_owned_only(ct, q0, qc, 1)),
                                      pha.to_device(_owned_only(ct_b, q0, qc, 1)), evk, d_out3)
         out["mul_owned"] = pha.to_host(prod)[:, q0:q0 + qc].copy()
@@ -102,7 +101,7 @@ def test_keyswitch_rotation_rescale(gpu, pha, orc, world, size_p, chain_index):
         out["rot_owned"] = pha.to_host(d_rot)[:, q0:q0 + qc].copy()
 
         if size_ql > 1:
-            d_dst = pha.to_device(np.full((2, size_ql - 1, N), POISON, dtype=np.uint64))
+            d_dst = pha.to_device(np.full((2, size_ql - 1, n), POISON, dtype=np.uint64))
             ev.rescale_to_next(chain_index, pha.to_device(_owned_only(ct, q0, qc, 1)), 2, d_dst)
             ev.gather_limbs(chain_index, [d_dst[0], d_dst[1]], size_ql - 1)
             out["rs_full"] = pha.to_host(d_dst)
@@ -119,6 +118,32 @@ def test_keyswitch_rotation_rescale(gpu, pha, orc, world, size_p, chain_index):
         assert (res["mul_owned"] == exp_mul[:, q0:q0 + qc]).all(), f"rank {rank} HMult + relinearise"
         if exp_rs is not None:
             assert (res["rs_full"] == exp_rs).all(), f"rank {rank} rescale"
+
+
+@pytest.mark.parametrize("world,size_p,chain_index", [(2, 2, 1), (3, 2, 2), (8, 2, 1), (4, 1, 1), (3, 3, 1), (2, 3, 3),
+                                                      (5, 1, 4), (4, 3, 2), (5, 2, 1), (1, 2, 1)])
+def test_keyswitch_rotation_rescale(gpu, pha, orc, world, size_p, chain_index):
+    _check_world(gpu, pha, orc, LOG_N, orc.coeff_modulus_create(N, [45] * 6 + [55] * size_p), size_p, chain_index, world)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_geometry_and_world(gpu, pha, orc, seed):
+    """the same checks with the shape drawn: N = 2^11 .. 2^13, alpha 1 .. 4, dnum 1 .. 4, primes of 36 .. 60 bits in any mix,
+    any level with two limbs or more, 1 .. 8 ranks (more ranks than limbs included: some ranks then own nothing)"""
+    rng = np.random.default_rng(7000 + seed)
+    log_n = int(rng.choice([11, 12, 13]))
+    alpha = int(rng.integers(1, 5))
+    dnum = max(int(rng.integers(1, 5)), 2 if alpha == 1 else 1)
+    size_q = alpha * dnum
+    q_bits = [int(b) for b in rng.integers(36, 61, size_q)]
+    p_bits = [int(b) for b in rng.integers(45, 61, alpha)]
+    chain_index = int(rng.integers(1, size_q))
+    world = int(rng.integers(1, 9))
+    mods = orc.coeff_modulus_create(1 << log_n, q_bits + p_bits)
+    try:
+        _check_world(gpu, pha, orc, log_n, mods, alpha, chain_index, world)
+    except AssertionError as e:
+        raise AssertionError(f"seed {seed}: N=2^{log_n} alpha={alpha} Q={q_bits} P={p_bits} chain_index={chain_index} world={world}: {e}")
 
 
 def test_window_validation(gpu, pha, orc):
