@@ -603,6 +603,9 @@ __global__ __launch_bounds__(256) void apply_galois_ntt_kernel(uint64_t *dst, co
 // ---------------------------------------------------------------------------------------------
 // dyadic ciphertext product (src/polymath.cu:468-537): d0 = a0 b0, d1 = a0 b1 + a1 b0, d2 = a1 b1
 // ---------------------------------------------------------------------------------------------
+#ifndef PHA_TENSOR_FP64
+#define PHA_TENSOR_FP64 1
+#endif
 template <bool SQUARE>
 __global__ __launch_bounds__(256) void tensor_prod_2x2_kernel(const uint64_t *op1, const uint64_t *op2,
                                                               const DModulus *mod, uint64_t *res, uint32_t n,
@@ -619,16 +622,32 @@ __global__ __launch_bounds__(256) void tensor_prod_2x2_kernel(const uint64_t *op
     const ulonglong2 b0 = SQUARE ? a0 : *reinterpret_cast<const ulonglong2 *>(op2 + id);
     const ulonglong2 b1 = SQUARE ? a1 : *reinterpret_cast<const ulonglong2 *>(op2 + id + rc);
     ulonglong2 d0, d1, d2;
+    const uint64_t q = m.value;
+    if (PHA_TENSOR_FP64 && (q >> 50) == 0) {
+        // residues below 2^50 as integer-valued doubles (modarith.cuh: FpField): three exact products of 6 FP64 operations
+        // each instead of three 128-bit Barrett products; every stored word is the canonical residue, as on the other path
+        const FpField f(m);
+        auto one = [&](uint64_t x0, uint64_t x1, uint64_t y0, uint64_t y1, unsigned long long &r0, unsigned long long &r1, unsigned long long &r2) {
+            const double fa0 = f.from_u64(x0), fa1 = f.from_u64(x1), fb0 = f.from_u64(y0), fb1 = f.from_u64(y1);
+            const double p0 = f.mulmod(fa0, f.prep(fb0)), p2 = f.mulmod(fa1, f.prep(fb1));
+            const double pk = f.mulmod(fa0 + fa1, f.prep(fb0 + fb1));      // operands < 2q: |pk| <= (1/2 + 3 * 2^-53 * 4q) q
+            r0 = f.to_u64(f.canon(p0));
+            r1 = f.to_u64(f.canon(pk - p0 - p2));
+            r2 = f.to_u64(f.canon(p2));
+        };
+        one(a0.x, a1.x, b0.x, b1.x, d0.x, d1.x, d2.x);
+        one(a0.y, a1.y, b0.y, b1.y, d0.y, d1.y, d2.y);
+    } else {
     d0.x = mul_barrett(a0.x, b0.x, m);
     d0.y = mul_barrett(a0.y, b0.y, m);
     d2.x = mul_barrett(a1.x, b1.x, m);
     d2.y = mul_barrett(a1.y, b1.y, m);
     // Karatsuba form of the reference: (a0+a1)(b0+b1) - d0 - d2; operands < 2q, product < 2^124
-    const uint64_t q = m.value;
     uint64_t tx = mul_barrett(a0.x + a1.x, b0.x + b1.x, m) + 2 * q - d0.x - d2.x;
     uint64_t ty = mul_barrett(a0.y + a1.y, b0.y + b1.y, m) + 2 * q - d0.y - d2.y;
     d1.x = csub(csub(tx, q), q);
     d1.y = csub(csub(ty, q), q);
+    }
     if (times2) {
         d0 = ulonglong2{csub(d0.x + d0.x, q), csub(d0.y + d0.y, q)};
         d1 = ulonglong2{csub(d1.x + d1.x, q), csub(d1.y + d1.y, q)};
