@@ -93,3 +93,81 @@ def test_evaluator_entry_points_on_a_random_geometry(gpu, pha, orc, seed):
     for e, got, exp in zip(elts, outs, refs):
         assert (host(got) == exp).all(), f"rotate_hoisted elt {e}, " + what
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(28))
+def test_transform_variants_on_a_random_window(gpu, pha, orc, seed):
+    """The eight live transform entry points (include/ntt.cuh:47-94) on drawn shapes: N = 2^11 .. 2^17 (every tile plan: the
+    in-LDS kernel, 6 + 6 .. 8 + 8 stages, the split N = 2^17 plan), mixed prime sizes, a drawn limb window [start, start +
+    count), special-modulus table remap with and without an excluded range, out-of-place and scaled inverse, the fused
+    moddown epilogue -- against the oracle word for word, and the words outside the window must stay as they were."""
+    rng = np.random.default_rng(12000 + seed)
+    log_n = [11, 12, 13, 14, 15, 16, 17][seed % 7]
+    n = 1 << log_n
+    size_p = int(rng.integers(1, 4))
+    size_q = int(rng.integers(2, 7 if log_n < 16 else 5))
+    bits = [int(b) for b in rng.integers(40, 61, size_q)] + [int(b) for b in rng.integers(50, 61, size_p)]
+    mods = orc.coeff_modulus_create(n, bits)
+    ctx, o = pha.PhantomContext(log_n, mods, size_p), orc.Oracle(log_n, mods, size_p)
+    size_qp = size_q + size_p
+    what = f"seed {seed}: N=2^{log_n} bits={bits} size_p={size_p}"
+    dev, host = pha.to_device, lambda t: t.cpu().numpy().view(np.uint64)
+
+    # plain window [start, start + count) of a size_qp buffer (buffers are passed whole: limb indices are absolute)
+    count = int(rng.integers(1, size_qp + 1))
+    start = int(rng.integers(0, size_qp - count + 1))
+    win = slice(start, start + count)
+    x = o.uniform_poly(list(range(size_qp)), 1)
+    ref = x.copy()
+    o.nwt_forward_inplace(ref, count, start)
+    d = dev(x)
+    ctx.nwt_2d_radix8_forward_inplace(d, count, start)
+    assert (host(d) == ref).all(), f"forward window [{start}, {start + count}), " + what
+    out = dev(np.zeros_like(x))
+    ctx.nwt_2d_radix8_backward(out, d, count, start)
+    got = host(out)
+    assert (got[win] == x[win]).all() and not got[:start].any() and not got[start + count:].any(), "inverse out of place, " + what
+    ctx.nwt_2d_radix8_backward_inplace(d, count, start)
+    assert (host(d) == x).all(), "inverse in place, " + what
+    scale = np.array([int(rng.integers(1, int(m))) for m in o.moduli[:size_qp]], dtype=np.uint64)
+    shoup = np.array([(int(s_) << 64) // int(m) for s_, m in zip(scale, o.moduli[:size_qp])], dtype=np.uint64)
+    sref = np.zeros_like(x)
+    o.nwt_backward_scale(sref, ref, count, start, scale)
+    sout = dev(np.zeros_like(x))
+    ctx.nwt_2d_radix8_backward_scale(sout, dev(ref), count, start, dev(scale), dev(shoup))
+    assert (host(sout) == sref).all(), "scaled inverse, " + what
+
+    # Q_l u P buffer: the last size_p limbs use the key-level tables; an excluded range inside the Q_l part
+    size_ql = int(rng.integers(1, size_q + 1))
+    qlp = size_ql + size_p
+    tidx = list(range(size_ql)) + list(range(size_q, size_qp))
+    y = o.uniform_poly(tidx, 2)
+    ref = y.copy()
+    o.nwt_forward_inplace_special(ref, qlp, 0, size_qp, size_p)
+    d = dev(y)
+    ctx.nwt_2d_radix8_forward_inplace_include_special_mod(d, qlp, 0, size_qp, size_p)
+    assert (host(d) == ref).all(), "special-modulus forward, " + what
+    e0 = int(rng.integers(0, size_ql))
+    e1 = int(rng.integers(e0 + 1, size_ql + 1))
+    ref2 = y.copy()
+    o.nwt_forward_inplace_special(ref2, qlp, 0, size_qp, size_p, e0, e1)
+    d = dev(y)
+    ctx.nwt_2d_radix8_forward_inplace_include_special_mod_exclude_range(d, qlp, 0, size_qp, size_p, e0, e1)
+    assert (host(d) == ref2).all() and (ref2[e0:e1] == y[e0:e1]).all(), f"excluded range [{e0}, {e1}), " + what
+    ref3 = ref.copy()
+    o.nwt_backward_inplace_special(ref3, size_p, size_ql, size_qp, size_p)
+    d = dev(ref)
+    ctx.nwt_2d_radix8_backward_inplace_include_special_mod(d, size_p, size_ql, size_qp, size_p)
+    assert (host(d) == ref3).all() and (ref3[size_ql:] == y[size_ql:]).all(), "special-modulus inverse, " + what
+
+    # forward transform of delta fused with (cx - .) * P^-1
+    lc = o.level_constants(size_ql)
+    pinv = lc["bigPInv_mod_q"]
+    pshoup = np.array([(int(s) << 64) // int(m) for s, m in zip(pinv, o.moduli[:size_ql])], dtype=np.uint64)
+    delta, cx = o.uniform_poly(list(range(size_ql)), 3), o.uniform_poly(list(range(size_ql)), 4)
+    fref = np.zeros_like(cx)
+    o.nwt_forward_fuse_moddown(fref, cx, pinv, delta.copy(), size_ql, 0)
+    dct = dev(np.zeros_like(cx))
+    ctx.nwt_2d_radix8_forward_inplace_fuse_moddown(dct, dev(cx), dev(pinv), dev(pshoup), dev(delta), size_ql, 0)
+    assert (host(dct) == fref).all(), "fused moddown epilogue, " + what
+    ctx.close()
