@@ -74,6 +74,9 @@ def parse(argv=None):
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4))
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: CPU-side rehearsal of the launcher path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spinup-ms", type=float, default=30.0,
+                    help="set-up, before the W warm-up steps: run the step untimed for this long so that the GPU's clocks have left "
+                         "their idle state (0: none); the timed region is unchanged -- exactly K steps between barrier + synchronize")
     ap.add_argument("--no-secondary", action="store_true", help="skip the HMult/rotate/bootstrap side measurements and roofline.int_path (profiling runs: kernel statistics then hold the headline chain only)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal without a GPU: the ranks rendezvous, time an empty step and print the line")
@@ -200,6 +203,24 @@ def keyswitch_cpu_baseline(rotate, budget_s=10.0):
     else:
         base.update(value=1e3 * el / done, unit="ms")
     return base
+
+
+def spin_up(step, ms, sync, fixed_steps=0):
+    """Set-up work, not part of the contract's W + K steps: a GPU that has just been handed to the process runs its first
+    milliseconds at idle clocks; with K = 20 steps of 70 us the timed region would otherwise measure that ramp.
+    fixed_steps: a step with collectives must run the same number of times on every rank -- a count instead of a duration."""
+    if ms <= 0:
+        return
+    if fixed_steps:
+        for _ in range(fixed_steps):
+            step()
+        sync()
+        return
+    t_end = time.perf_counter() + ms * 1e-3
+    while time.perf_counter() < t_end:
+        for _ in range(20):
+            step()
+        sync()
 
 
 def timed_steps(step, steps, warmup, dist, sync, device):
@@ -470,6 +491,7 @@ def run_config2(args, torch, pha, rank, world, dist):
         ctx.ntt_forward_batched(buf, POLYS, LIMBS, LIMBS, 0)
         ctx.ntt_backward_batched(buf, POLYS, LIMBS, LIMBS, 0)
 
+    spin_up(step, args.spinup_ms, torch.cuda.synchronize)
     elapsed = timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda")
     # size-independent property at full size: the round trips returned the input bit-for-bit
     assert torch.equal(buf, orig), "INTT(NTT(x)) != x after the timed region"
@@ -517,6 +539,7 @@ def run_config3(args, torch, pha, rank, world, dist):
     def step():
         ev.multiply_and_relin(1, ct1, ct2, evk, out3)
 
+    spin_up(step, args.spinup_ms, torch.cuda.synchronize, fixed_steps=100)   # all-gathers inside: same count on every rank
     elapsed = timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda")
     q0, qc, p0, pc = ev.windows(1)[rank]
     ndev = devices_used(torch, dist, world)
@@ -559,6 +582,7 @@ def run_config4(args, torch, pha, rank, world, dist):
         for grp in groups:
             ctx.apply_galois_batched(1, grp, elt, evk)
 
+    spin_up(step, args.spinup_ms, torch.cuda.synchronize, fixed_steps=3)
     elapsed = timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda")
     out = {
         "metric": "CKKS rotate (apply_galois + key switch) ciphertexts/s, 64 independent ciphertexts @N=2^16, 36 + 12 limbs",
