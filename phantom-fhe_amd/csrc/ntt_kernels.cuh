@@ -145,6 +145,40 @@ __device__ __forceinline__ void st_stream2(uint64_t *p, ulonglong2 v) {
 #endif
 }
 
+// Tile accesses through a buffer descriptor: a workgroup-uniform base (scalar registers), one 32-bit byte offset per lane
+// and a scalar offset per row group -- the 64-bit address arithmetic of a strided access (2-3 VALU instructions each)
+// moves to the scalar unit, and the stores are compiler-visible instructions instead of asm statements (LDS reads and
+// arithmetic are scheduled around them).  Stores carry sc1 like st_stream (write-through).
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kAuxSc1 = PHA_SC1_STORES ? 16 : 0;   // cache-policy bit 4 = sc1 on gfx94x/gfx950
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const uint64_t *ubase) {
+    // the base IS workgroup-uniform (it derives from blockIdx and kernel arguments); reading it from the first lane says so
+    // to the compiler where its own analysis gives up -- otherwise every access is wrapped in a waterfall loop
+    const uint64_t b = reinterpret_cast<uint64_t>(ubase);
+    // (the builtin returns a signed int: widen through uint32_t, or a low word with bit 31 set smears over the high word)
+    const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(b >> 32)));
+    const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(b)));
+    const uint64_t u = (static_cast<uint64_t>(hi) << 32) | lo;
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint64_t *>(u), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ uint64_t ld_tile(__amdgpu_buffer_rsrc_t r, uint32_t lane_byte_off, uint32_t uniform_byte_off) {
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_byte_off, uniform_byte_off, 0);
+    return (static_cast<uint64_t>(v.y) << 32) | v.x;
+}
+__device__ __forceinline__ void st_tile(__amdgpu_buffer_rsrc_t r, uint32_t lane_byte_off, uint32_t uniform_byte_off, uint64_t v) {
+    const u32x2_t w = {static_cast<uint32_t>(v), static_cast<uint32_t>(v >> 32)};
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, lane_byte_off, uniform_byte_off, kAuxSc1);
+}
+#ifndef PHA_BUF_MASK
+#define PHA_BUF_MASK 15   // bisecting aid: 1 forward column, 2 forward row, 4 inverse row, 8 inverse column kernel
+#endif
+__device__ __forceinline__ void st_tile2(__amdgpu_buffer_rsrc_t r, uint32_t lane_byte_off, uint32_t uniform_byte_off, ulonglong2 v) {
+    const u32x4_t w = {static_cast<uint32_t>(v.x), static_cast<uint32_t>(v.x >> 32), static_cast<uint32_t>(v.y),
+                       static_cast<uint32_t>(v.y >> 32)};
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, lane_byte_off, uniform_byte_off, kAuxSc1);
+}
+
 // Development aid (tools/scratch/trace_ntt.py): per-workgroup timestamps of the forward kernels' phases.
 #ifdef PHA_TRACE
 __device__ unsigned long long *pha_trace_buf;
@@ -425,8 +459,16 @@ __device__ __forceinline__ void fntt_col_load(uint64_t (&raw)[16], const uint64_
 #pragma unroll
     for (int g = 0; g < GA; g++) {
         const uint32_t gid = pha_tid() + kThreads * g, c = gid % C, r_lo = gid / C;
+        // uniform row pointer + one 32-bit lane offset for all 2^RA loads (scalar base, no 64-bit VALU address arithmetic)
+        const uint32_t off = (r_lo * n2 + c) * 8u;
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(base);
 #pragma unroll
-        for (int j = 0; j < (1 << RA); j++) raw[(g << RA) + j] = base[static_cast<size_t>((j << RB) | r_lo) * n2 + c];
+        for (int j = 0; j < (1 << RA); j++) {
+            if (PHA_BUF_MASK & 1)
+                raw[(g << RA) + j] = ld_tile(rs, off, static_cast<uint32_t>(j << RB) * n2 * 8u);
+            else
+                raw[(g << RA) + j] = base[static_cast<size_t>((j << RB) | r_lo) * n2 + c];
+        }
     }
 }
 // SC1: the result is stored write-through (hand-off to the row pass inside one launch, ntt_fused.cuh)
@@ -465,13 +507,16 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, const uint64_t (&ra
             ct_radix<RB, RA>(x, pre, f);
         else
             ct_radix<RB, RA>(x, CanonTw<TW>{tw, (root << RA) + r_hi}, f);
+        const uint32_t off = ((r_hi << RB) * n2 + c) * 8u;
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(base);
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) {
-            uint64_t *p = &base[static_cast<size_t>((r_hi << RB) | j) * n2 + c];
             if (SC1)
-                st_sc1(p, F::raw(x[j]));
+                st_sc1(&base[static_cast<size_t>((r_hi << RB) | j) * n2 + c], F::raw(x[j]));
+            else if (PHA_BUF_MASK & 1)
+                st_tile(rs, off, static_cast<uint32_t>(j) * n2 * 8u, F::raw(x[j]));
             else
-                st_stream(p, F::raw(x[j]));
+                st_stream(&base[static_cast<size_t>((r_hi << RB) | j) * n2 + c], F::raw(x[j]));
         }
     }
     PHA_TRACE_MARK(3);
@@ -665,10 +710,19 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, const uint64_t (&ra
     __syncthreads();
 
     const typename F::twt c = f.make_cst(cst, cst_shoup);
+    // all eight LDS reads first, so that their latency is paid once and not per result store
+    typename F::elem lv0[8], lv1[8];
+    const __amdgpu_buffer_rsrc_t out_rs = tile_rsrc(out);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint32_t e = (i * kThreads + t) * 2;
-        typename F::elem v0 = F::unraw(lds[lds_row(e)]), v1 = F::unraw(lds[lds_row(e + 1)]);
+        lv0[i] = F::unraw(lds[lds_row(e)]);
+        lv1[i] = F::unraw(lds[lds_row(e + 1)]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t e = (i * kThreads + t) * 2;
+        const typename F::elem v0 = lv0[i], v1 = lv1[i];
         ulonglong2 v;
         if (EPI != EPI_NONE) {
             // (cx - NTT(delta)) * PInv mod q  (src/ntt/ntt_moddown.cu:209-214,
@@ -694,7 +748,13 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, const uint64_t (&ra
             v.x = f.to_u64(v0);
             v.y = f.to_u64(v1);
         }
-        st_stream2(out + e, v);
+        if (PHA_BUF_MASK & 2)
+            // the whole offset in the lane operand, the scalar offset an immediate 0: a 16-byte store whose scalar offset is
+            // a REGISTER gets no wait state from the compiler before its data registers are overwritten, and the hardware
+            // needs one (measured: sparse wrong words in the epilogue kernels; the asm form carries its own s_nop)
+            st_tile2(out_rs, t * 16u + i * kThreads * 16u, 0, v);
+        else
+            st_stream2(out + e, v);
     }
 }
 
@@ -758,6 +818,7 @@ __device__ __forceinline__ void intt_row_body(uint64_t *lds, const uint64_t (&ra
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
     const uint32_t t = threadIdx.x;
     const typename F::twt unused{};
+    const __amdgpu_buffer_rsrc_t dst_rs = tile_rsrc(dst);
     double theta = 0.0;
     if (kCanGen && twg) theta = gen_theta(f, twg, lds_omega, ti, t);      // omega reaches LDS before the first barrier
 #pragma unroll
@@ -805,7 +866,12 @@ __device__ __forceinline__ void intt_row_body(uint64_t *lds, const uint64_t (&ra
         else
             gs_radix<RA, false>(x, CanonTw<TW>{tw, n1 + ti * RW + a}, f, unused);
 #pragma unroll
-        for (int j = 0; j < (1 << RA); j++) st_stream(&dst[a * L + ((j << RB) | b_lo)], F::raw(x[j]));
+        for (int j = 0; j < (1 << RA); j++) {
+            if (PHA_BUF_MASK & 4)
+                st_tile(dst_rs, (a * L + b_lo) * 8u, (j << RB) * 8u, F::raw(x[j]));
+            else
+                st_stream(&dst[a * L + ((j << RB) | b_lo)], F::raw(x[j]));
+        }
     }
 }
 
@@ -843,8 +909,15 @@ __device__ __forceinline__ void intt_col_load(uint64_t (&raw)[16], const uint64_
 #pragma unroll
     for (int g = 0; g < GB; g++) {
         const uint32_t gid = threadIdx.x + kThreads * g, c = gid % C, r_hi = gid / C;
+        const uint32_t off = ((r_hi << RB) * n2 + c) * 8u;
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(base);
 #pragma unroll
-        for (int j = 0; j < (1 << RB); j++) raw[(g << RB) + j] = base[static_cast<size_t>((r_hi << RB) | j) * n2 + c];
+        for (int j = 0; j < (1 << RB); j++) {
+            if (PHA_BUF_MASK & 8)
+                raw[(g << RB) + j] = ld_tile(rs, off, static_cast<uint32_t>(j) * n2 * 8u);
+            else
+                raw[(g << RB) + j] = base[static_cast<size_t>((r_hi << RB) | j) * n2 + c];
+        }
     }
 }
 template <int S1, int RA, int EPI, bool SPLIT, class F>
@@ -855,6 +928,7 @@ __device__ __forceinline__ void intt_col_body(uint64_t *lds, const uint64_t (&ra
     using TW = typename F::twl;
     const TW *tw = reinterpret_cast<const TW *>(tw_raw);
     const uint32_t t = threadIdx.x;
+    const __amdgpu_buffer_rsrc_t base_rs = tile_rsrc(base);
     const typename F::twt ninv = f.make_cst(n_inv, n_inv_shoup);
 #pragma unroll
     for (int g = 0; g < GB; g++) {
@@ -883,7 +957,10 @@ __device__ __forceinline__ void intt_col_body(uint64_t *lds, const uint64_t (&ra
             typename F::elem v = SPLIT ? f.canon_inv(x[j]) : x[j];
             // fused bconv phase 1 (src/ntt/ntt_modup.cu:212-318)
             if (EPI == EPI_SCALE) v = f.scale(v, c_scale);
-            st_stream(&base[static_cast<size_t>((j << RB) | r_lo) * n2 + c], f.to_u64(v));
+            if (PHA_BUF_MASK & 8)
+                st_tile(base_rs, (r_lo * n2 + c) * 8u, static_cast<uint32_t>(j << RB) * n2 * 8u, f.to_u64(v));
+            else
+                st_stream(&base[static_cast<size_t>((j << RB) | r_lo) * n2 + c], f.to_u64(v));
         }
     }
 }
