@@ -408,6 +408,23 @@ __device__ __forceinline__ uint32_t lds_col(uint32_t r, uint32_t c) {
     return r * C + c + (C == 16 ? (r >> RB) * 16 : 0);
 #endif
 }
+// The same index for row (hi << RB) | lo with the part that depends on the (compile-time) register index split off as a
+// constant: lds_col<C, RB>((j << RB) | r_lo, c) = lds_col_lo(r_lo, c) + j * kColHiStep, and
+// lds_col<C, RB>((r_hi << RB) | j, c) = lds_col_hi(r_hi, c) + j * C -- the 16 accesses of a pass then share one address
+// register and differ in their immediate offsets (the padded image only; the swizzled one has no such form)
+template <int C, int RB>
+struct LdsColSplit {
+    static constexpr bool kSplit = !PHA_LDS_SWIZZLE;
+    static constexpr uint32_t kHiStep = (static_cast<uint32_t>(C) << RB) + (C == 16 ? 16u : 0u);
+    __device__ __forceinline__ static uint32_t by_hi(uint32_t j, uint32_t r_lo, uint32_t c) {      // row (j << RB) | r_lo
+        if (kSplit) return r_lo * C + c + j * kHiStep;
+        return lds_col<C, RB>((j << RB) | r_lo, c);
+    }
+    __device__ __forceinline__ static uint32_t by_lo(uint32_t r_hi, uint32_t j, uint32_t c) {      // row (r_hi << RB) | j
+        if (kSplit) return r_hi * kHiStep + c + j * C;
+        return lds_col<C, RB>((r_hi << RB) | j, c);
+    }
+};
 // Row tile, seen as 128-B rows of eight 16-B chunks.  Padded: 16 B per 128 B so that the last pass's ds_read_b128
 // (lane stride 128 B) is conflict-free.  Swizzled: chunk ^= (row >> 1) & 7 spreads the 16 lanes of such a read
 // over the 16 chunks of a bank row, and row ^= (row >> 4) & 1 separates the first pass's half-waves (16 rows apart).
@@ -420,6 +437,18 @@ __device__ __forceinline__ uint32_t lds_row(uint32_t e) {
 #endif
 }
 
+// lds_row(x + y) with y a compile-time constant whose sum with x carries nothing out of the low four bits: the padded
+// index is then additive, lds_row(x) + lds_row(y), and the constant part becomes the immediate offset of the LDS access
+// (16 accesses share one address register).  The swizzled image has no such form.
+__device__ __forceinline__ uint32_t lds_row_add(uint32_t x_index, uint32_t x, uint32_t y) {
+#if PHA_LDS_SWIZZLE
+    (void)x_index;
+    return lds_row(x + y);
+#else
+    (void)x;
+    return x_index + (y + ((y >> 4) << 1));
+#endif
+}
 // Between the two kernels of a transform the buffer holds the field's raw lazy representation
 // (an unreduced integer, or the bits of a double on the FP64 path); only the first kernel's
 // input and the last kernel's output are residues in the caller's format.
@@ -488,7 +517,7 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, const uint64_t (&ra
         for (int j = 0; j < (1 << RA); j++) x[j] = f.from_u64(raw[(g << RA) + j]);
         ct_radix<RA, 0>(x, CanonTw<TW>{tw, root}, f);
 #pragma unroll
-        for (int j = 0; j < (1 << RA); j++) lds[lds_col<C, RB>((j << RB) | r_lo, c)] = F::raw(x[j]);
+        for (int j = 0; j < (1 << RA); j++) lds[LdsColSplit<C, RB>::by_hi(j, r_lo, c)] = F::raw(x[j]);
     }
     PHA_TRACE_MARK(1);
     // one group per lane and 8-byte twiddles: the second pass's 2^RB - 1 twiddles are requested before the barrier
@@ -502,7 +531,7 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, const uint64_t (&ra
         const uint32_t gid = t + kThreads * g, c = gid % C, r_hi = gid / C;
         typename F::elem x[1 << RB];
 #pragma unroll
-        for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(lds[lds_col<C, RB>((r_hi << RB) | j, c)]);
+        for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(lds[LdsColSplit<C, RB>::by_lo(r_hi, j, c)]);
         if constexpr (kPre)
             ct_radix<RB, RA>(x, pre, f);
         else
@@ -666,17 +695,18 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, const uint64_t (&ra
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) x[j] = F::unraw(raw[(g << RA) + j]);
         ct_radix<RA, 0>(x, CanonTw<TW>{tw, n1 + ti * RW + a}, f);
+        const uint32_t ia = lds_row(a * L + b_lo);
 #pragma unroll
-        for (int j = 0; j < (1 << RA); j++) lds[lds_row(a * L + ((j << RB) | b_lo))] = F::raw(x[j]);
+        for (int j = 0; j < (1 << RA); j++) lds[lds_row_add(ia, a * L + b_lo, j << RB)] = F::raw(x[j]);
     }
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < GD; g++) {
-        const uint32_t gid = t + kThreads * g, e0 = gid << RB;
+        const uint32_t gid = t + kThreads * g, e0 = gid << RB, i0 = lds_row(e0);
         const uint32_t ggid = ti * (kTile >> RB) + gid;
         typename F::elem x[1 << RB];
 #pragma unroll
-        for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(lds[lds_row(e0 + j)]);
+        for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(lds[lds_row_add(i0, e0, j)]);
         if constexpr (kCanGen) {
             if (twg) {
                 ct_radix<RB, RA>(x, GenTw(f, lds_omega, theta), f);
@@ -691,7 +721,7 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, const uint64_t (&ra
             ct_radix<RB, RA>(x, LastPassTw<RB, TW>{twd}, f);
         }
 #pragma unroll
-        for (int j = 0; j < (1 << RB); j++) lds[lds_row(e0 + j)] = F::raw(f.canon_fwd(x[j]));
+        for (int j = 0; j < (1 << RB); j++) lds[lds_row_add(i0, e0, j)] = F::raw(f.canon_fwd(x[j]));
     }
 #if PHA_EPI_PREFETCH
     // The epilogue's operand streams are requested here, where the butterfly registers are dead and the workgroup is
@@ -715,9 +745,9 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, const uint64_t (&ra
     const __amdgpu_buffer_rsrc_t out_rs = tile_rsrc(out);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const uint32_t e = (i * kThreads + t) * 2;
-        lv0[i] = F::unraw(lds[lds_row(e)]);
-        lv1[i] = F::unraw(lds[lds_row(e + 1)]);
+        const uint32_t it = lds_row(2 * t);
+        lv0[i] = F::unraw(lds[lds_row_add(it, 2 * t, i * kThreads * 2)]);
+        lv1[i] = F::unraw(lds[lds_row_add(it, 2 * t, i * kThreads * 2 + 1)]);
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -823,18 +853,18 @@ __device__ __forceinline__ void intt_row_body(uint64_t *lds, const uint64_t (&ra
     if (kCanGen && twg) theta = gen_theta(f, twg, lds_omega, ti, t);      // omega reaches LDS before the first barrier
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const uint32_t e = (i * kThreads + t) * 2;
-        lds[lds_row(e)] = F::raw(f.from_u64(raw[2 * i]));
-        lds[lds_row(e + 1)] = F::raw(f.from_u64(raw[2 * i + 1]));
+        const uint32_t it = lds_row(2 * t);
+        lds[lds_row_add(it, 2 * t, i * kThreads * 2)] = F::raw(f.from_u64(raw[2 * i]));
+        lds[lds_row_add(it, 2 * t, i * kThreads * 2 + 1)] = F::raw(f.from_u64(raw[2 * i + 1]));
     }
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < GD; g++) {
-        const uint32_t gid = t + kThreads * g, e0 = gid << RB;
+        const uint32_t gid = t + kThreads * g, e0 = gid << RB, i0 = lds_row(e0);
         const uint32_t ggid = ti * (kTile >> RB) + gid;
         typename F::elem x[1 << RB];
 #pragma unroll
-        for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(lds[lds_row(e0 + j)]);
+        for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(lds[lds_row_add(i0, e0, j)]);
         if constexpr (kCanGen) {
             if (twg) {
                 gs_radix<RB, false>(x, GenTw(f, lds_omega, theta), f, unused);
@@ -849,7 +879,7 @@ __device__ __forceinline__ void intt_row_body(uint64_t *lds, const uint64_t (&ra
             gs_radix<RB, false>(x, LastPassTw<RB, TW>{twd}, f, unused);
         }
 #pragma unroll
-        for (int j = 0; j < (1 << RB); j++) lds[lds_row(e0 + j)] = F::raw(x[j]);
+        for (int j = 0; j < (1 << RB); j++) lds[lds_row_add(i0, e0, j)] = F::raw(x[j]);
     }
     constexpr bool kPre = PHA_TW_PREFETCH && GC == 1 && sizeof(TW) == 8;
     PreTw<kPre ? RA : 1, TW> pre;
@@ -859,8 +889,9 @@ __device__ __forceinline__ void intt_row_body(uint64_t *lds, const uint64_t (&ra
     for (int g = 0; g < GC; g++) {
         const uint32_t gid = t + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;
         typename F::elem x[1 << RA];
+        const uint32_t ia = lds_row(a * L + b_lo);
 #pragma unroll
-        for (int j = 0; j < (1 << RA); j++) x[j] = F::unraw(lds[lds_row(a * L + ((j << RB) | b_lo))]);
+        for (int j = 0; j < (1 << RA); j++) x[j] = F::unraw(lds[lds_row_add(ia, a * L + b_lo, j << RB)]);
         if constexpr (kPre)
             gs_radix<RA, false>(x, pre, f, unused);
         else
@@ -938,7 +969,7 @@ __device__ __forceinline__ void intt_col_body(uint64_t *lds, const uint64_t (&ra
         for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(raw[(g << RB) + j]);
         gs_radix<RB, false>(x, CanonTw<TW>{tw, (root << RA) + r_hi}, f, ninv);
 #pragma unroll
-        for (int j = 0; j < (1 << RB); j++) lds[lds_col<C, RB>((r_hi << RB) | j, c)] = F::raw(x[j]);
+        for (int j = 0; j < (1 << RB); j++) lds[LdsColSplit<C, RB>::by_lo(r_hi, j, c)] = F::raw(x[j]);
     }
     __syncthreads();
     const typename F::twt c_scale = f.make_cst(cst, cst_shoup);
@@ -947,7 +978,7 @@ __device__ __forceinline__ void intt_col_body(uint64_t *lds, const uint64_t (&ra
         const uint32_t gid = t + kThreads * g, c = gid % C, r_lo = gid / C;
         typename F::elem x[1 << RA];
 #pragma unroll
-        for (int j = 0; j < (1 << RA); j++) x[j] = F::unraw(lds[lds_col<C, RB>((j << RB) | r_lo, c)]);
+        for (int j = 0; j < (1 << RA); j++) x[j] = F::unraw(lds[LdsColSplit<C, RB>::by_hi(j, r_lo, c)]);
         if (SPLIT)      // a subtree: its last stage is an ordinary one; N^-1 waits for split_inv_kernel
             gs_radix<RA, false>(x, CanonTw<TW>{tw, root}, f, ninv);
         else
