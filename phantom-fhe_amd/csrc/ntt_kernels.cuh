@@ -31,7 +31,8 @@ namespace pha {
 //  * a timing-only build with a 30 KiB image (what keeping each lane's own element of the exchange in a register
 //    would allow) did put all 1152 workgroups on the chip at once, but the kernel span only went from 16.6 to
 //    15.2 us: every workgroup ran slower (median 9.1 against 7.7 us) — the memory system, not the tail, is the limit.
-// Both stay selectable for re-measurement; every variant passes the parity tests.
+// PHA_LDS_SWIZZLE stays selectable for re-measurement and passes the parity tests; PHA_TILE_LOG=11 was measured in round 2
+// and no longer builds since ntt_fused.cuh (written for 4096-coefficient tiles) is part of the library.
 #ifndef PHA_TILE_LOG
 #define PHA_TILE_LOG 12
 #endif
