@@ -209,6 +209,30 @@ __device__ unsigned long long *pha_trace_buf;
 #define PHA_TRACE_EXIT()
 #endif
 
+// Wave priorities (experiment, -DPHA_GEN_PRIO=1/2/3; profiles/EXPERIMENTS.md 3.13): 1 = a workgroup's waves take the
+// priority 3 - min(3, blockIdx / 256) at entry (the four workgroups a CU holds are one of each 256-block dispatch round,
+// so the oldest issues first and reaches its stores while the others still compute); 2 = the same plus priority 3 behind
+// the exchange barrier (whoever is in its last pass goes first); 3 = only the latter.
+#ifndef PHA_GEN_PRIO
+#define PHA_GEN_PRIO 0
+#endif
+__device__ __forceinline__ void prio_entry() {
+#if PHA_GEN_PRIO == 1 || PHA_GEN_PRIO == 2
+    const uint32_t gen = blockIdx.x >> 8;
+    if (gen == 0)
+        __builtin_amdgcn_s_setprio(3);
+    else if (gen == 1)
+        __builtin_amdgcn_s_setprio(2);
+    else if (gen == 2)
+        __builtin_amdgcn_s_setprio(1);
+#endif
+}
+__device__ __forceinline__ void prio_late() {
+#if PHA_GEN_PRIO >= 2
+    __builtin_amdgcn_s_setprio(3);
+#endif
+}
+
 // returns false when this workgroup has nothing to do (ragged last digit)
 __device__ __forceinline__ bool resolve_limb(const LimbMap &m, uint32_t poly, uint32_t li, uint32_t &twr, uint32_t &tidx) {
     uint32_t es = m.excl_start, ee = m.excl_end;
@@ -526,6 +550,7 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, const uint64_t (&ra
     PreTw<kPre ? RB : 1, TW> pre;
     if constexpr (kPre) pre = prefetch_tw<RB, TW>(tw, (root << RA) + t / C);
     __syncthreads();
+    prio_late();
     PHA_TRACE_MARK(2);
 #pragma unroll
     for (int g = 0; g < GB; g++) {
@@ -571,6 +596,7 @@ __global__ PHA_NTT_BOUNDS void fntt_col_kernel(uint64_t *data, size_t poly_strid
     uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + st.offset + st.tile * C;
     uint64_t raw[16];
     fntt_col_load<S1, RA>(raw, base, st.n2);
+    prio_entry();
     const DModulus mod = T.mod[tidx];
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     if (use_fp64(T, mod))
@@ -701,6 +727,7 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, const uint64_t (&ra
         for (int j = 0; j < (1 << RA); j++) lds[lds_row_add(ia, a * L + b_lo, j << RB)] = F::raw(x[j]);
     }
     __syncthreads();
+    prio_late();
 #pragma unroll
     for (int g = 0; g < GD; g++) {
         const uint32_t gid = t + kThreads * g, e0 = gid << RB, i0 = lds_row(e0);
@@ -805,6 +832,7 @@ __global__ PHA_NTT_BOUNDS void fntt_row_kernel(uint64_t *data, size_t poly_strid
     uint64_t *base = data + poly * poly_stride + limb_off;
     uint64_t raw[16];
     fntt_row_load<S2, RA>(raw, base);
+    prio_entry();
     const DModulus mod = T.mod[tidx];
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     const tw_t *twd = T.twD + static_cast<size_t>(tidx) * T.twD_stride;
@@ -886,6 +914,7 @@ __device__ __forceinline__ void intt_row_body(uint64_t *lds, const uint64_t (&ra
     PreTw<kPre ? RA : 1, TW> pre;
     if constexpr (kPre) pre = prefetch_tw<RA, TW>(tw, n1 + ti * RW + (t >> RB));
     __syncthreads();
+    prio_late();
 #pragma unroll
     for (int g = 0; g < GC; g++) {
         const uint32_t gid = t + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;
@@ -923,6 +952,7 @@ __global__ PHA_NTT_BOUNDS void intt_row_kernel(uint64_t *out, const uint64_t *in
     const size_t out_off = inv_out_offset(lm, poly, poly_stride, twr, n) + static_cast<size_t>(ti) * kTile;
     uint64_t raw[16];
     intt_row_load(raw, in + off);
+    prio_entry();
     const DModulus mod = T.mod[tidx];
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     const tw_t *twd = T.twD + static_cast<size_t>(tidx) * T.twD_stride;
@@ -973,6 +1003,7 @@ __device__ __forceinline__ void intt_col_body(uint64_t *lds, const uint64_t (&ra
         for (int j = 0; j < (1 << RB); j++) lds[LdsColSplit<C, RB>::by_lo(r_hi, j, c)] = F::raw(x[j]);
     }
     __syncthreads();
+    prio_late();
     const typename F::twt c_scale = f.make_cst(cst, cst_shoup);
 #pragma unroll
     for (int g = 0; g < GA; g++) {
@@ -1012,6 +1043,7 @@ __global__ PHA_NTT_BOUNDS void intt_col_kernel(uint64_t *data, size_t poly_strid
     uint64_t *base = data + inv_out_offset(lm, poly, poly_stride, twr, n) + st.offset + st.tile * C;
     uint64_t raw[16];
     intt_col_load<S1, RA>(raw, base, st.n2);
+    prio_entry();
     const DModulus mod = T.mod[tidx];
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
     const uint64_t n_inv = T.n_inv[tidx], n_inv_shoup = T.n_inv_shoup[tidx];
