@@ -377,8 +377,14 @@ __device__ __forceinline__ double gen_theta<FpField>(const FpField &f, const dou
 // radix-2^R decimation-in-time block: stage s uses twiddle node*2^s + jb on sub-block jb.
 // G0 = index of the block's first stage within its kernel; the field policies (modarith.cuh)
 // reduce on even kernel-local stages only.
+// -DPHA_NO_MATH=1: timing-only build without butterflies (wrong results): what the loads, the LDS exchange and the stores of
+// a pass cost in the same launch structure (profiles/EXPERIMENTS.md 3.14)
+#ifndef PHA_NO_MATH
+#define PHA_NO_MATH 0
+#endif
 template <int R, int G0, class F, class Tw>
 __device__ __forceinline__ void ct_radix(typename F::elem (&x)[1 << R], const Tw &tw, const F &f) {
+    if (PHA_NO_MATH) return;
 #pragma unroll
     for (int s = 0; s < R; s++) {
         const int half = 1 << (R - 1 - s);
@@ -402,6 +408,7 @@ __device__ __forceinline__ void ct_radix(typename F::elem (&x)[1 << R], const Tw
 template <int R, bool LAST, class F, class Tw>
 __device__ __forceinline__ void gs_radix(typename F::elem (&x)[1 << R], const Tw &tw, const F &f,
                                          const typename F::twt &n_inv) {
+    if (PHA_NO_MATH) return;
 #pragma unroll
     for (int s = R - 1; s >= (LAST ? 1 : 0); s--) {
         const int half = 1 << (R - 1 - s);
