@@ -47,7 +47,11 @@ constexpr int kLdsWords = kTile;
 #define PHA_NTT_BOUNDS __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5)))
 #else
 constexpr int kLdsWords = kTile + 512;
+#ifndef PHA_NTT_MIN_WAVES
 #define PHA_NTT_BOUNDS __launch_bounds__(kThreads)
+#else
+#define PHA_NTT_BOUNDS __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PHA_NTT_MIN_WAVES)))
+#endif
 #endif
 
 struct LimbMap {
@@ -69,6 +73,10 @@ struct LimbMap {
                                     // e.g. the last limb of every poly gathered into a [polys][N] buffer (rescale)
     uint32_t polys_magic;           // ceil(2^32 / polys): decode_block divides by polys with one multiply (set by
                                     // the launcher; exact for dividends < 2^20 and polys <= 2^11)
+    const uint64_t *bcast_src;      // forward column kernel, BCAST variant: every limb's input is this ONE limb in
+    size_t bcast_poly_stride;       // coefficient form ([polys] limbs, bcast_poly_stride words apart) reduced modulo the
+                                    // limb's prime on load -- the broadcast of rescale and of the alpha = 1 moddown
+                                    // (src/rns.cu:1125-1136, src/rns_bconv.cu:691-707) without its pass through memory
 };
 
 struct NttTables {
@@ -588,7 +596,7 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, const uint64_t (&ra
 #endif
 }
 
-template <int S1, int RA, bool NARROW>
+template <int S1, int RA, bool NARROW, bool BCAST = false>
 __global__ PHA_NTT_BOUNDS void fntt_col_kernel(uint64_t *data, size_t poly_stride, NttTables T, LimbMap lm) {
     constexpr int C = kTile >> S1;
     __shared__ uint64_t lds[kLdsWords];
@@ -602,10 +610,14 @@ __global__ PHA_NTT_BOUNDS void fntt_col_kernel(uint64_t *data, size_t poly_strid
     const SubTree st = sub_tree<S1>(T, ti);
     uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + st.offset + st.tile * C;
     uint64_t raw[16];
-    fntt_col_load<S1, RA>(raw, base, st.n2);
+    fntt_col_load<S1, RA>(raw, BCAST ? lm.bcast_src + poly * lm.bcast_poly_stride + st.offset + st.tile * C : base, st.n2);
     prio_entry();
     const DModulus mod = T.mod[tidx];
     const tw_t *tw = T.tw + static_cast<size_t>(tidx) * n;
+    if (BCAST) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) raw[j] = barrett64(raw[j], mod.value, mod.ratio1);
+    }
     if (use_fp64(T, mod))
         fntt_col_body<S1, RA>(lds, raw, base, tw, st.n2, st.root, FpField(mod));
     else

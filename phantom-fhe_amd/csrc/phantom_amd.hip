@@ -189,6 +189,7 @@ struct pha_context {
     DevBuf<tw_t> d_tw, d_itw, d_twD, d_itwD;
     DevBuf<double> d_twG, d_itwG;     // generators of the last pass's twiddles (FP64 limbs; numth.hpp build_generator_table)
     bool col8 = false;                // PHA_COL8=1: forward column pass with eight coefficients per lane (experiment)
+    bool bcast_fused = true;          // PHA_BCAST_FUSED=0: the single-limb broadcast of rescale / alpha = 1 moddown as its own pass
     bool gen_tw = false;              // the row passes derive their last-pass twiddles (PHA_GEN_TW=0: read them from twD)
     DevBuf<uint64_t> d_n_inv, d_n_inv_shoup;
     uint32_t twD_stride = 0;
@@ -400,6 +401,10 @@ int upload_tables(pha_context *ctx) {
         const char *c8 = getenv("PHA_COL8");
         ctx->col8 = c8 && c8[0] == '1' && kTileLog == 12;
     }
+    {
+        const char *e = getenv("PHA_BCAST_FUSED");
+        ctx->bcast_fused = !(e && e[0] == '0');
+    }
     HIP_TRY(ctx->d_mod.upload(mods));
     HIP_TRY(ctx->d_n_inv.upload(ninv));
     HIP_TRY(ctx->d_n_inv_shoup.upload(ninv_s));
@@ -440,6 +445,13 @@ int make_range(const pha_context *ctx, size_t count, size_t start, size_t size_Q
 
 template <int S, int RA>
 void launch_fcol(bool narrow, dim3 grid, hipStream_t st, uint64_t *data, size_t ps, const NttTables &T, const LimbMap &lm) {
+    if (lm.bcast_src) {
+        if (narrow)
+            hipLaunchKernelGGL((fntt_col_kernel<S, RA, true, true>), grid, dim3(kThreads), 0, st, data, ps, T, lm);
+        else
+            hipLaunchKernelGGL((fntt_col_kernel<S, RA, false, true>), grid, dim3(kThreads), 0, st, data, ps, T, lm);
+        return;
+    }
     if (narrow)
         hipLaunchKernelGGL((fntt_col_kernel<S, RA, true>), grid, dim3(kThreads), 0, st, data, ps, T, lm);
     else
@@ -529,7 +541,8 @@ int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stri
             hipLaunchKernelGGL((small_fntt_kernel<EPI_NONE>), g, dim3(256), 0, st, data, poly_stride, T, rr.lm, ep);
         return check_launch("forward NTT (N = 2^11)");
     }
-    if (ctx->fused && phases == 3 && epi == EPI_NONE && !T.split && ctx->plan.s1 == 8 && ctx->plan.s2 == 8 && ctx->fused_nq) {
+    if (ctx->fused && phases == 3 && epi == EPI_NONE && !T.split && ctx->plan.s1 == 8 && ctx->plan.s2 == 8 && ctx->fused_nq &&
+        !r.lm.bcast_src) {
         const size_t tiles = ctx->n >> kTileLog, units = static_cast<size_t>(r.active) * polys;
         if (units >= ctx->fused_min_units && units <= kFusedMaxUnits) {
             set_placement(rr.lm, false, polys);
@@ -567,6 +580,31 @@ int ntt_forward(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stri
                (launch_frow<7, 4>(ctx->narrow, epi, grid, st, data, poly_stride, T, rr.lm, ep)),
                (launch_frow<8, 4>(ctx->narrow, epi, grid, st, data, poly_stride, T, rr.lm, ep)));
     return check_launch("forward NTT");
+}
+
+// data[p][j] = NTT(src[p] mod q_j) (+ epilogue) for the limbs j of `r`, src = ONE limb per poly in coefficient form,
+// src_stride words apart: the broadcast of rescale_to_next and of the alpha = 1 moddown (src/rns.cu:1125-1136,
+// src/rns_bconv.cu:691-707) followed by the forward transform.  The column kernel reduces the source on load
+// (fntt_col_kernel<.., BCAST>), so the broadcast costs no pass through memory; where that kernel does not run (N = 2^11,
+// N = 2^17, the eight-per-lane column pass, PHA_BCAST_FUSED=0) reduce_single_limb_kernel writes the residues first.
+bool bcast_in_column_pass(const pha_context *ctx) {
+    return ctx->bcast_fused && !ctx->plan.small && !ctx->fwd_tables().split && !(ctx->col8 && ctx->plan.s1 == 8);
+}
+int ntt_forward_bcast(pha_context *ctx, uint64_t *data, size_t polys, size_t poly_stride, const NttRange &r, int epi,
+                      const Epilogue &ep, hipStream_t st, const uint64_t *src, size_t src_stride) {
+    if (!r.active || !polys) return PHA_OK;
+    // (the fallback below indexes the moduli by buffer limb: no special-modulus remap, no excluded range)
+    if (bcast_in_column_pass(ctx) && r.lm.excl_end <= r.lm.excl_start && !r.lm.size_P) {
+        NttRange rr = r;
+        rr.lm.bcast_src = src;
+        rr.lm.bcast_poly_stride = src_stride;
+        return ntt_forward(ctx, data, polys, poly_stride, rr, epi, ep, st);
+    }
+    const uint32_t n = static_cast<uint32_t>(ctx->n);
+    hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(n / 512, static_cast<uint32_t>(polys)), dim3(256), 0, st, data, src,
+                       ctx->d_mod.p, r.lm.start, r.lm.start + r.lm.count, n, poly_stride, src_stride);
+    PHA_TRY(check_launch("reduce_single_limb"));
+    return ntt_forward(ctx, data, polys, poly_stride, r, epi, ep, st);
 }
 
 // out_limb0 / out_poly_stride: see LimbMap (where the transformed limbs land in `out`; default: where they were in `in`)
@@ -754,6 +792,21 @@ int do_modup(pha_context *ctx, LevelTool *lt, uint64_t *dst, const uint64_t *cks
     Epilogue ep{};
     if (alpha == 1) {
         PHA_TRY(ntt_backward(ctx, t_cks, cks, 1, 0, r, EPI_NONE, ep, st));
+        if (bcast_in_column_pass(ctx)) {
+            // every digit is ONE limb: digit d's other limbs are limb d of t_cks modulo their primes, which the forward
+            // column kernel forms on load (poly d reads t_cks + d * n); only the own limbs are copied, if asked for
+            if (copy_own)
+                HIP_TRY(hipMemcpy2DAsync(dst, (size_QlP + 1) * n * sizeof(uint64_t), cks, n * sizeof(uint64_t),
+                                         n * sizeof(uint64_t), size_Ql, hipMemcpyDeviceToDevice, st));
+            NttRange rb;
+            PHA_TRY(make_range(ctx, size_QlP, 0, ctx->size_QP, alpha, 0, 0, rb));
+            rb.lm.digit_alpha = 1u;
+            rb.lm.digit_limit = static_cast<uint32_t>(size_Ql);
+            rb.active = rb.lm.active = static_cast<uint32_t>(size_QlP - 1);
+            rb.lm.bcast_src = t_cks;
+            rb.lm.bcast_poly_stride = n;
+            return ntt_forward(ctx, dst, lt->beta, size_QlP * n, rb, EPI_NONE, Epilogue{}, st);
+        }
         hipLaunchKernelGGL(modup_single_p_kernel, dim3(static_cast<uint32_t>(n / 256), static_cast<uint32_t>(lt->beta)),
                            dim3(256), 0, st, dst, cks, t_cks, ctx->d_mod.p, static_cast<uint32_t>(size_Ql),
                            static_cast<uint32_t>(ctx->size_Q), static_cast<uint32_t>(n), 0u,
@@ -856,10 +909,6 @@ int do_moddown(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *cx, uint
     uint64_t *cp = cx + size_Ql * n;
     if (alpha == 1) {
         PHA_TRY(ntt_backward(ctx, cx, cx, polys, size_QlP * n, rp, EPI_NONE, Epilogue{}, st));
-        hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(static_cast<uint32_t>(n / 512), static_cast<uint32_t>(polys)),
-                           dim3(256), 0, st, delta, cp, ctx->d_mod.p, 0u, static_cast<uint32_t>(size_Ql),
-                           static_cast<uint32_t>(n), size_Ql * n, size_QlP * n);
-        PHA_TRY(check_launch("reduce_single_limb"));
     } else {
         // INTT fused with bconv phase 1 (x PHatInv mod p_k); constants indexed by buffer limb
         Epilogue ep{};
@@ -883,6 +932,9 @@ int do_moddown(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *cx, uint
     ep.cst_shoup = lt->bigPInv.s.p;
     ep.out_poly_stride = size_Ql * n;
     ep.sub_poly_stride = size_QlP * n;
+    if (alpha == 1)   // the single special limb, broadcast over Q_l inside the transform
+        return ntt_forward_bcast(ctx, delta, polys, size_Ql * n, rq, addend ? EPI_SUB_MUL_ADD : EPI_SUB_MUL, ep, st, cp,
+                                 size_QlP * n);
     return ntt_forward(ctx, delta, polys, size_Ql * n, rq, addend ? EPI_SUB_MUL_ADD : EPI_SUB_MUL, ep, st);
 }
 
@@ -977,8 +1029,9 @@ int do_keyswitch(pha_context *ctx, LevelTool *lt, uint64_t *ct, const uint64_t *
     PHA_TRY(ensure_workspace(ctx, (lt->beta * size_QlP + 2 * size_QlP + 2 * size_Ql) * n, &ws, st));
     WsLease ws_lease(ctx, st);
     uint64_t *t_mod_up = ws, *cx = t_mod_up + lt->beta * size_QlP * n, *scratch = cx + 2 * size_QlP * n;
-    // alpha > 1: the digits' own limbs stay in c2 and the inner product reads them there (36 MiB less traffic at configs[2])
-    const bool in_place_own = ctx->size_P > 1;
+    // the digits' own limbs stay in c2 and the inner product reads them there (36 MiB less traffic at configs[2]); with one
+    // special prime the modup copies them only where its broadcast kernel writes them anyway
+    const bool in_place_own = ctx->size_P > 1 || bcast_in_column_pass(ctx);
     PHA_TRY(do_modup(ctx, lt, t_mod_up, c2, scratch, st, !in_place_own));
     PHA_TRY(do_inner_prod(ctx, lt, cx, t_mod_up, evks, st, nullptr, in_place_own ? c2 : nullptr));
     // both polys' moddown in one launch sequence, add_to_ct fused into the NTT epilogue
@@ -990,10 +1043,6 @@ int do_rescale(pha_context *ctx, LevelTool *lt, const uint64_t *src, const uint6
                size_t cipher_size, uint64_t *dst, hipStream_t st) {
     // last_coeff[p * last_stride ...]: INTT'ed last limb of poly p
     const size_t n = ctx->n, size_Ql = lt->size_Ql, next = size_Ql - 1;
-    hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(static_cast<uint32_t>(n / 512), static_cast<uint32_t>(cipher_size)),
-                       dim3(256), 0, st, dst, last_coeff, ctx->d_mod.p, 0u, static_cast<uint32_t>(next),
-                       static_cast<uint32_t>(n), next * n, last_stride);
-    PHA_TRY(check_launch("reduce_single_limb"));
     NttRange r;
     PHA_TRY(make_range(ctx, next, 0, 0, 0, 0, 0, r));
     Epilogue ep{};
@@ -1003,7 +1052,7 @@ int do_rescale(pha_context *ctx, LevelTool *lt, const uint64_t *src, const uint6
     ep.cst_shoup = lt->inv_q_last.s.p;
     ep.out_poly_stride = next * n;
     ep.sub_poly_stride = size_Ql * n;
-    return ntt_forward(ctx, dst, cipher_size, next * n, r, EPI_SUB_MUL, ep, st);
+    return ntt_forward_bcast(ctx, dst, cipher_size, next * n, r, EPI_SUB_MUL, ep, st, last_coeff, last_stride);
 }
 
 // rescale_to_next (src/evaluate.cu:585-616, src/rns.cu:1157-1181) with the caller's scratch [cipher_size][n]: the last limb of
@@ -1193,12 +1242,7 @@ int lp_moddown_finish(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *c
     uint64_t *delta;
     PHA_TRY(ensure_workspace(ctx, 2 * size_Ql * n, &delta, st));
     WsLease ws_lease(ctx, st);
-    if (alpha == 1) {
-        hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(static_cast<uint32_t>(n / 512), 2u), dim3(256), 0, st, delta,
-                           p_coeff + (p_rows ? p_rows[0] : 0) * n, ctx->d_mod.p, static_cast<uint32_t>(w.q0),
-                           static_cast<uint32_t>(w.q0 + w.qc), static_cast<uint32_t>(n), size_Ql * n, p_stride);
-        PHA_TRY(check_launch("reduce_single_limb"));
-    } else {
+    if (alpha != 1) {
         BconvBatch bt{size_Ql * n, p_stride, 0, 0, 0, nullptr, 0, 0, 0, 0};
         if (p_rows) {
             if (alpha > kBconvMaxRows) return fail(PHA_ERR_INVALID_ARGUMENT, "a p_coeff row table holds at most %u special primes", kBconvMaxRows);
@@ -1223,6 +1267,9 @@ int lp_moddown_finish(pha_context *ctx, LevelTool *lt, uint64_t *ct, uint64_t *c
     ep.cst_shoup = lt->bigPInv.s.p;
     ep.out_poly_stride = size_Ql * n;
     ep.sub_poly_stride = size_QlP * n;
+    if (alpha == 1)
+        return ntt_forward_bcast(ctx, delta, 2, size_Ql * n, rq, EPI_SUB_MUL_ADD, ep, st, p_coeff + (p_rows ? p_rows[0] : 0) * n,
+                                 p_stride);
     return ntt_forward(ctx, delta, 2, size_Ql * n, rq, EPI_SUB_MUL_ADD, ep, st);
 }
 
@@ -1231,10 +1278,6 @@ int lp_rescale_finish(pha_context *ctx, LevelTool *lt, const uint64_t *src, cons
     const size_t n = ctx->n, size_Ql = lt->size_Ql, next = size_Ql - 1;
     const size_t a = std::min(w.q0, next), b = std::min(w.q0 + w.qc, next);
     if (a >= b) return PHA_OK;
-    hipLaunchKernelGGL(reduce_single_limb_kernel, dim3(static_cast<uint32_t>(n / 512), static_cast<uint32_t>(cipher_size)),
-                       dim3(256), 0, st, dst, last_coeff, ctx->d_mod.p, static_cast<uint32_t>(a), static_cast<uint32_t>(b),
-                       static_cast<uint32_t>(n), next * n, n);
-    PHA_TRY(check_launch("reduce_single_limb"));
     NttRange r;
     PHA_TRY(make_range(ctx, b - a, a, 0, 0, 0, 0, r));
     Epilogue ep{};
@@ -1244,7 +1287,7 @@ int lp_rescale_finish(pha_context *ctx, LevelTool *lt, const uint64_t *src, cons
     ep.cst_shoup = lt->inv_q_last.s.p;
     ep.out_poly_stride = next * n;
     ep.sub_poly_stride = size_Ql * n;
-    return ntt_forward(ctx, dst, cipher_size, next * n, r, EPI_SUB_MUL, ep, st);
+    return ntt_forward_bcast(ctx, dst, cipher_size, next * n, r, EPI_SUB_MUL, ep, st, last_coeff, n);
 }
 
 // ---- key generation / encryption / decryption -------------------------------

@@ -158,3 +158,33 @@ def test_eight_per_lane_column_pass_equals_default(gpu, pha, log_n, bits):
     assert gpu.equal(a, x)
     col8.close()
     base.close()
+
+
+@pytest.mark.parametrize("log_n,q_bits,size_p,p_bits", [(16, [60] + [50] * 7, 1, 60), (15, [55, 50, 45, 60], 1, 58), (16, [60] * 3 + [50] * 3, 2, 60)])
+def test_broadcast_inside_the_column_pass_equals_separate_pass(gpu, pha, log_n, q_bits, size_p, p_bits):
+    """rescale_to_next and the alpha = 1 moddown broadcast ONE coefficient-form limb over the remaining limbs
+    (src/rns.cu:1125-1136, src/rns_bconv.cu:691-707).  By default the forward column kernel reduces it on load
+    (fntt_col_kernel<.., BCAST>); PHA_BCAST_FUSED=0 writes the residues in a pass of their own first.  Same words, on
+    integer and FP64 limbs, for rescale (any alpha) and for a key switch with one special prime."""
+    n = 1 << log_n
+    mods = pha.coeff_modulus_create(n, q_bits + [p_bits] * size_p)
+    fused = _ctx(pha, log_n, mods, size_p, PHA_BCAST_FUSED=1)
+    plain = _ctx(pha, log_n, mods, size_p, PHA_BCAST_FUSED=0)
+    size_q = len(q_bits)
+    src = gpu.stack([_uniform(gpu, mods, mods[:size_q], n, 21), _uniform(gpu, mods, mods[:size_q], n, 22)])
+    a, b = gpu.empty((2, size_q - 1, n), dtype=gpu.int64, device="cuda"), gpu.empty((2, size_q - 1, n), dtype=gpu.int64, device="cuda")
+    fused.rescale_to_next(1, src, 2, a)
+    plain.rescale_to_next(1, src, 2, b)
+    assert gpu.equal(a, b), "rescale differs"
+    if size_p == 1:
+        evk_t = [gpu.stack([_uniform(gpu, mods, mods, n, 30 + 2 * d), _uniform(gpu, mods, mods, n, 31 + 2 * d)]) for d in range(size_q)]
+        evk = pha.EvalKey(evk_t)
+        ct = gpu.stack([_uniform(gpu, mods, mods[:size_q], n, 23), _uniform(gpu, mods, mods[:size_q], n, 24)])
+        c2 = _uniform(gpu, mods, mods[:size_q], n, 25)
+        ca, cb = ct.clone(), ct.clone()
+        fused.keyswitch_inplace(1, ca, c2, evk)
+        plain.keyswitch_inplace(1, cb, c2, evk)
+        gpu.cuda.synchronize()
+        assert gpu.equal(ca, cb), "key switch with one special prime differs"
+    fused.close()
+    plain.close()
