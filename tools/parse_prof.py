@@ -71,6 +71,7 @@ head = os.popen(f"git -C {ROOT} rev-parse --short HEAD 2>/dev/null").read().stri
 for d in (summary, latest):
     d["source_hash"] = bench.kernel_source_hash()
     d["git_head_at_parse"] = head
+    d["tag"] = tag
 json.dump(summary, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 json.dump(latest, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
