@@ -241,6 +241,14 @@ __device__ __forceinline__ void prio_late() {
 #endif
 }
 
+// A value that is the same in every lane of the workgroup BY CONSTRUCTION (it derives from blockIdx and kernel arguments
+// only), said to the compiler where its own analysis gives up (the block decode divides): what is indexed by it -- the
+// modulus, N^-1, the epilogue constants, the table and tile base pointers -- is then fetched through the scalar cache and
+// kept in scalar registers instead of queueing behind the tile's vector loads.
+__device__ __forceinline__ uint32_t uniform(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
+}
+
 // returns false when this workgroup has nothing to do (ragged last digit)
 __device__ __forceinline__ bool resolve_limb(const LimbMap &m, uint32_t poly, uint32_t li, uint32_t &twr, uint32_t &tidx) {
     uint32_t es = m.excl_start, ee = m.excl_end;
@@ -346,7 +354,7 @@ __device__ __forceinline__ PreTw<R, TW> prefetch_tw(const TW *tw, uint32_t node)
     return r;
 }
 #ifndef PHA_TW_PREFETCH
-#define PHA_TW_PREFETCH 1
+#define PHA_TW_PREFETCH 2     // 1: the pass behind the exchange barrier only (round-3 default until r3y); 2: also the first pass
 #endif
 
 template <int RB, class TW>
@@ -561,7 +569,7 @@ __device__ __forceinline__ void fntt_col_body(uint64_t *lds, const uint64_t (&ra
     }
     PHA_TRACE_MARK(1);
     // one group per lane and 8-byte twiddles: the second pass's 2^RB - 1 twiddles are requested before the barrier
-    constexpr bool kPre = PHA_TW_PREFETCH && GB == 1 && sizeof(TW) == 8;
+    constexpr bool kPre = PHA_TW_PREFETCH && GB == 1 && (sizeof(TW) == 8 || PHA_TW_PREFETCH >= 3);
     PreTw<kPre ? RB : 1, TW> pre;
     if constexpr (kPre) pre = prefetch_tw<RB, TW>(tw, (root << RA) + t / C);
     __syncthreads();
@@ -604,9 +612,11 @@ __global__ PHA_NTT_BOUNDS void fntt_col_kernel(uint64_t *data, size_t poly_strid
     PHA_TRACE_ENTRY();
     BlockWork bw;
     if (!decode_block(blockIdx.x, lm, tiles, bw)) return;
-    const uint32_t poly = bw.poly, ti = bw.ti;
+    const uint32_t poly = uniform(bw.poly), ti = uniform(bw.ti);
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
+    twr = uniform(twr);
+    tidx = uniform(tidx);
     const SubTree st = sub_tree<S1>(T, ti);
     uint64_t *base = data + poly * poly_stride + static_cast<size_t>(twr) * n + st.offset + st.tile * C;
     uint64_t raw[16];
@@ -734,13 +744,21 @@ __device__ __forceinline__ void fntt_row_body(uint64_t *lds, const uint64_t (&ra
     const uint32_t t = pha_tid();
     double theta = 0.0;
     if (kCanGen && twg) theta = gen_theta(f, twg, lds_omega, ti, t);      // omega reaches LDS before the first barrier
+    // one group per lane and 8-byte twiddles: the first pass's 2^RA - 1 twiddles are requested here, behind the tile loads
+    // and before their data are touched, instead of stage by stage with a wait behind each load
+    constexpr bool kPreA = PHA_TW_PREFETCH >= 2 && GC == 1 && (sizeof(TW) == 8 || PHA_TW_PREFETCH >= 3);
+    PreTw<kPreA ? RA : 1, TW> preA;
+    if constexpr (kPreA) preA = prefetch_tw<RA, TW>(tw, n1 + ti * RW + (t >> RB));
 #pragma unroll
     for (int g = 0; g < GC; g++) {
         const uint32_t gid = t + kThreads * g, b_lo = gid & ((1u << RB) - 1), a = gid >> RB;
         typename F::elem x[1 << RA];
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) x[j] = F::unraw(raw[(g << RA) + j]);
-        ct_radix<RA, 0>(x, CanonTw<TW>{tw, n1 + ti * RW + a}, f);
+        if constexpr (kPreA)
+            ct_radix<RA, 0>(x, preA, f);
+        else
+            ct_radix<RA, 0>(x, CanonTw<TW>{tw, n1 + ti * RW + a}, f);
         const uint32_t ia = lds_row(a * L + b_lo);
 #pragma unroll
         for (int j = 0; j < (1 << RA); j++) lds[lds_row_add(ia, a * L + b_lo, j << RB)] = F::raw(x[j]);
@@ -843,9 +861,11 @@ __global__ PHA_NTT_BOUNDS void fntt_row_kernel(uint64_t *data, size_t poly_strid
     const uint32_t n = 1u << T.log_n, n1 = n >> S2, tiles = n >> kTileLog;
     BlockWork bw;
     if (!decode_block(blockIdx.x, lm, tiles, bw)) return;
-    const uint32_t poly = bw.poly, ti = bw.ti;
+    const uint32_t poly = uniform(bw.poly), ti = uniform(bw.ti);
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
+    twr = uniform(twr);
+    tidx = uniform(tidx);
     const double *twg = T.twG ? T.twG + static_cast<size_t>(tidx) * kGenWords : nullptr;
     const size_t limb_off = static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
     uint64_t *base = data + poly * poly_stride + limb_off;
@@ -929,7 +949,7 @@ __device__ __forceinline__ void intt_row_body(uint64_t *lds, const uint64_t (&ra
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) lds[lds_row_add(i0, e0, j)] = F::raw(x[j]);
     }
-    constexpr bool kPre = PHA_TW_PREFETCH && GC == 1 && sizeof(TW) == 8;
+    constexpr bool kPre = PHA_TW_PREFETCH && GC == 1 && (sizeof(TW) == 8 || PHA_TW_PREFETCH >= 3);
     PreTw<kPre ? RA : 1, TW> pre;
     if constexpr (kPre) pre = prefetch_tw<RA, TW>(tw, n1 + ti * RW + (t >> RB));
     __syncthreads();
@@ -963,9 +983,11 @@ __global__ PHA_NTT_BOUNDS void intt_row_kernel(uint64_t *out, const uint64_t *in
     const uint32_t n = 1u << T.log_n, n1 = n >> S2, tiles = n >> kTileLog;
     BlockWork bw;
     if (!decode_block(blockIdx.x, lm, tiles, bw)) return;
-    const uint32_t poly = bw.poly, ti = bw.ti;
+    const uint32_t poly = uniform(bw.poly), ti = uniform(bw.ti);
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
+    twr = uniform(twr);
+    tidx = uniform(tidx);
     const double *twg = T.twG ? T.twG + static_cast<size_t>(tidx) * kGenWords : nullptr;
     const size_t off = poly * poly_stride + static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * kTile;
     const size_t out_off = inv_out_offset(lm, poly, poly_stride, twr, n) + static_cast<size_t>(ti) * kTile;
@@ -1011,13 +1033,19 @@ __device__ __forceinline__ void intt_col_body(uint64_t *lds, const uint64_t (&ra
     const uint32_t t = threadIdx.x;
     const __amdgpu_buffer_rsrc_t base_rs = tile_rsrc(base);
     const typename F::twt ninv = f.make_cst(n_inv, n_inv_shoup);
+    constexpr bool kPreB = PHA_TW_PREFETCH >= 2 && GB == 1 && (sizeof(TW) == 8 || PHA_TW_PREFETCH >= 3);      // as in fntt_row_body
+    PreTw<kPreB ? RB : 1, TW> preB;
+    if constexpr (kPreB) preB = prefetch_tw<RB, TW>(tw, (root << RA) + t / C);
 #pragma unroll
     for (int g = 0; g < GB; g++) {
         const uint32_t gid = t + kThreads * g, c = gid % C, r_hi = gid / C;
         typename F::elem x[1 << RB];
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) x[j] = F::unraw(raw[(g << RB) + j]);
-        gs_radix<RB, false>(x, CanonTw<TW>{tw, (root << RA) + r_hi}, f, ninv);
+        if constexpr (kPreB)
+            gs_radix<RB, false>(x, preB, f, ninv);
+        else
+            gs_radix<RB, false>(x, CanonTw<TW>{tw, (root << RA) + r_hi}, f, ninv);
 #pragma unroll
         for (int j = 0; j < (1 << RB); j++) lds[LdsColSplit<C, RB>::by_lo(r_hi, j, c)] = F::raw(x[j]);
     }
@@ -1055,9 +1083,11 @@ __global__ PHA_NTT_BOUNDS void intt_col_kernel(uint64_t *data, size_t poly_strid
     const uint32_t n = 1u << T.log_n, tiles = n >> kTileLog;
     BlockWork bw;
     if (!decode_block(blockIdx.x, lm, tiles, bw)) return;
-    const uint32_t poly = bw.poly, ti = bw.ti;
+    const uint32_t poly = uniform(bw.poly), ti = uniform(bw.ti);
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
+    twr = uniform(twr);
+    tidx = uniform(tidx);
     const SubTree st = sub_tree<S1>(T, ti);
     uint64_t *base = data + inv_out_offset(lm, poly, poly_stride, twr, n) + st.offset + st.tile * C;
     uint64_t raw[16];
@@ -1183,9 +1213,11 @@ __global__ __launch_bounds__(256) void split_fwd_kernel(uint64_t *data, size_t p
     const uint32_t n = 1u << T.log_n, half = n >> 1, tiles = half >> 12;
     BlockWork bw;
     if (!decode_block(blockIdx.x, lm, tiles, bw)) return;
-    const uint32_t poly = bw.poly, ti = bw.ti;
+    const uint32_t poly = uniform(bw.poly), ti = uniform(bw.ti);
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
+    twr = uniform(twr);
+    tidx = uniform(tidx);
     uint64_t *lo = data + poly * poly_stride + static_cast<size_t>(twr) * n + static_cast<size_t>(ti) * 4096, *hi = lo + half;
     const DModulus mod = T.mod[tidx];
     const uint64_t q = mod.value, w = root_twiddle(T, mod, T.tw + static_cast<size_t>(tidx) * n);
@@ -1208,9 +1240,11 @@ __global__ __launch_bounds__(256) void split_inv_kernel(uint64_t *data, size_t p
     const uint32_t n = 1u << T.log_n, half = n >> 1, tiles = half >> 12;
     BlockWork bw;
     if (!decode_block(blockIdx.x, lm, tiles, bw)) return;
-    const uint32_t poly = bw.poly, ti = bw.ti;
+    const uint32_t poly = uniform(bw.poly), ti = uniform(bw.ti);
     uint32_t twr, tidx;
     if (!resolve_limb(lm, poly, bw.li, twr, tidx)) return;
+    twr = uniform(twr);
+    tidx = uniform(tidx);
     uint64_t *lo = data + inv_out_offset(lm, poly, poly_stride, twr, n) + static_cast<size_t>(ti) * 4096, *hi = lo + half;
     const DModulus mod = T.mod[tidx];
     const uint64_t q = mod.value, w = root_twiddle(T, mod, T.tw + static_cast<size_t>(tidx) * n);
