@@ -281,9 +281,63 @@ static int exchange_mode() {
     return 0;
 }
 
+
+// ---- mode "policy": the in-place pass of a transform kernel (read 16 B, write 16 B to the same address, 36 MiB, resident in
+// the Infinity Cache as in the benchmark loop) under the cache-policy bits a store / load can carry on gfx950 ----------
+#define POLICY_KERNEL(NAME, LD, ST)                                                                              \
+    __global__ __launch_bounds__(256) void NAME(ulonglong2 *buf, size_t n) {                                      \
+        for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {                      \
+            u64x2_p v;                                                                                            \
+            asm volatile("global_load_dwordx4 %0, %1, off" LD "\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(buf + i) : "memory"); \
+            v.x += 1;                                                                                             \
+            asm volatile("global_store_dwordx4 %0, %1, off" ST "\n\ts_nop 1" : : "v"(buf + i), "v"(v) : "memory");  \
+        }                                                                                                         \
+    }
+typedef unsigned long long u64x2_p __attribute__((ext_vector_type(2)));
+POLICY_KERNEL(pol_plain, "", "")
+POLICY_KERNEL(pol_st_sc1, "", " sc1")
+POLICY_KERNEL(pol_st_sc0, "", " sc0")
+POLICY_KERNEL(pol_st_sc0sc1, "", " sc0 sc1")
+POLICY_KERNEL(pol_st_nt, "", " nt")
+POLICY_KERNEL(pol_st_ntsc1, "", " sc1 nt")
+POLICY_KERNEL(pol_st_ntsc0sc1, "", " sc0 sc1 nt")
+POLICY_KERNEL(pol_ld_nt_st_sc1, " nt", " sc1")
+POLICY_KERNEL(pol_ld_sc1_st_sc1, " sc1", " sc1")
+POLICY_KERNEL(pol_ld_nt_st_ntsc1, " nt", " sc1 nt")
+int policy_mode() {
+    void *buf;
+    const size_t bytes = 36ull << 20, n = bytes / 16;
+    CHECK(hipMalloc(&buf, 2 * bytes));
+    CHECK(hipMemset(buf, 1, 2 * bytes));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    typedef void (*kern_t)(ulonglong2 *, size_t);
+    const struct { const char *name; kern_t k; } ks[] = {
+        {"load plain, store plain", pol_plain}, {"store sc1", pol_st_sc1}, {"store sc0", pol_st_sc0}, {"store sc0 sc1", pol_st_sc0sc1},
+        {"store nt", pol_st_nt}, {"store sc1 nt", pol_st_ntsc1}, {"store sc0 sc1 nt", pol_st_ntsc0sc1},
+        {"load nt, store sc1", pol_ld_nt_st_sc1}, {"load sc1, store sc1", pol_ld_sc1_st_sc1}, {"load nt, store sc1 nt", pol_ld_nt_st_ntsc1}};
+    for (int round = 0; round < 2; round++)
+        for (int grid : {1152, 4608})
+            for (const auto &e : ks) {
+                // two buffers alternating, like the passes of a forward + inverse step over 2 x 36 limbs
+                for (int r = 0; r < 10; r++) hipLaunchKernelGGL(e.k, dim3(grid), dim3(256), 0, 0, (ulonglong2 *)buf + (r & 1) * n, n);
+                CHECK(hipDeviceSynchronize());
+                CHECK(hipEventRecord(e0));
+                const int reps = 100;
+                for (int r = 0; r < reps; r++) hipLaunchKernelGGL(e.k, dim3(grid), dim3(256), 0, 0, (ulonglong2 *)buf + (r & 1) * n, n);
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                printf("round %d grid %4d  %-26s %6.2f us per 36 MiB in-place pass = %5.2f TB/s\n", round, grid, e.name, 1e3 * ms / reps,
+                       2.0 * bytes / (ms / reps * 1e-3) / 1e12);
+            }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc > 1 && std::string(argv[1]) == "exchange") return exchange_mode();
     if (argc > 1 && std::string(argv[1]) == "mix") return mix_mode();
+    if (argc > 1 && std::string(argv[1]) == "policy") return policy_mode();
     if (argc > 1) {
         // calibration mode for the FETCH_SIZE / WRITE_SIZE counters: known byte counts
         // (512 MiB read + 512 MiB written per launch), 3 launches of each access width
