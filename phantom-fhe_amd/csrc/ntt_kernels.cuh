@@ -353,6 +353,11 @@ __device__ __forceinline__ PreTw<R, TW> prefetch_tw(const TW *tw, uint32_t node)
         for (int jb = 0; jb < (1 << s); jb++) r.w[(1 << s) - 1 + jb] = tw[(node << s) + jb];
     return r;
 }
+// the inverse column kernel has the registers for the integer path's 16-byte {w, Shoup companion} records too (124 VGPRs;
+// in the inverse row kernel the same costs the FP64 limbs more than it gives the integer ones: profiles/EXPERIMENTS.md 3.16)
+#ifndef PHA_TW_PREFETCH_INV16
+#define PHA_TW_PREFETCH_INV16 1
+#endif
 #ifndef PHA_TW_PREFETCH
 #define PHA_TW_PREFETCH 2     // 1: the pass behind the exchange barrier only (round-3 default until r3y); 2: also the first pass
 #endif
@@ -1033,7 +1038,7 @@ __device__ __forceinline__ void intt_col_body(uint64_t *lds, const uint64_t (&ra
     const uint32_t t = threadIdx.x;
     const __amdgpu_buffer_rsrc_t base_rs = tile_rsrc(base);
     const typename F::twt ninv = f.make_cst(n_inv, n_inv_shoup);
-    constexpr bool kPreB = PHA_TW_PREFETCH >= 2 && GB == 1 && (sizeof(TW) == 8 || PHA_TW_PREFETCH >= 3);      // as in fntt_row_body
+    constexpr bool kPreB = PHA_TW_PREFETCH >= 2 && GB == 1 && (sizeof(TW) == 8 || PHA_TW_PREFETCH >= 3 || PHA_TW_PREFETCH_INV16);      // as in fntt_row_body
     PreTw<kPreB ? RB : 1, TW> preB;
     if constexpr (kPreB) preB = prefetch_tw<RB, TW>(tw, (root << RA) + t / C);
 #pragma unroll
