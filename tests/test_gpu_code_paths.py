@@ -160,7 +160,8 @@ def test_eight_per_lane_column_pass_equals_default(gpu, pha, log_n, bits):
     base.close()
 
 
-@pytest.mark.parametrize("log_n,q_bits,size_p,p_bits", [(16, [60] + [50] * 7, 1, 60), (15, [55, 50, 45, 60], 1, 58), (16, [60] * 3 + [50] * 3, 2, 60)])
+@pytest.mark.parametrize("log_n,q_bits,size_p,p_bits", [(16, [60] + [50] * 7, 1, 60), (15, [55, 50, 45, 60], 1, 58), (16, [60] * 3 + [50] * 3, 2, 60),
+                                                        (13, [54, 40, 40, 40, 50], 1, 55), (12, [50, 36, 36], 1, 50), (14, [60, 45, 45, 45], 3, 60)])
 def test_broadcast_inside_the_column_pass_equals_separate_pass(gpu, pha, log_n, q_bits, size_p, p_bits):
     """rescale_to_next and the alpha = 1 moddown broadcast ONE coefficient-form limb over the remaining limbs
     (src/rns.cu:1125-1136, src/rns_bconv.cu:691-707).  By default the forward column kernel reduces it on load
@@ -186,5 +187,19 @@ def test_broadcast_inside_the_column_pass_equals_separate_pass(gpu, pha, log_n, 
         plain.keyswitch_inplace(1, cb, c2, evk)
         gpu.cuda.synchronize()
         assert gpu.equal(ca, cb), "key switch with one special prime differs"
+    if size_q > 2:      # one level down: a shorter chain, the same special prime(s)
+        lo = src[:, :size_q - 1].contiguous()
+        a2, b2 = gpu.empty((2, size_q - 2, n), dtype=gpu.int64, device="cuda"), gpu.empty((2, size_q - 2, n), dtype=gpu.int64, device="cuda")
+        fused.rescale_to_next(2, lo, 2, a2)
+        plain.rescale_to_next(2, lo, 2, b2)
+        assert gpu.equal(a2, b2), "rescale one level down differs"
+        if size_p == 1:
+            ct2 = gpu.stack([_uniform(gpu, mods, mods[:size_q - 1], n, 26), _uniform(gpu, mods, mods[:size_q - 1], n, 27)])
+            c22 = _uniform(gpu, mods, mods[:size_q - 1], n, 28)
+            ca, cb = ct2.clone(), ct2.clone()
+            fused.keyswitch_inplace(2, ca, c22, evk)
+            plain.keyswitch_inplace(2, cb, c22, evk)
+            gpu.cuda.synchronize()
+            assert gpu.equal(ca, cb), "key switch one level down differs"
     fused.close()
     plain.close()
