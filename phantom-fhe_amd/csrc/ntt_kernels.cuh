@@ -403,9 +403,43 @@ __device__ __forceinline__ double gen_theta<FpField>(const FpField &f, const dou
 #ifndef PHA_NO_MATH
 #define PHA_NO_MATH 0
 #endif
+#ifndef PHA_TW_PIPELINE
+#define PHA_TW_PIPELINE 1     // 0: every stage fetches its own twiddles (A/B: profiles/EXPERIMENTS.md 3.19)
+#endif
 template <int R, int G0, class F, class Tw>
 __device__ __forceinline__ void ct_radix(typename F::elem (&x)[1 << R], const Tw &tw, const F &f) {
     if (PHA_NO_MATH) return;
+#if PHA_TW_PIPELINE
+    // the twiddles of stage s + 1 are requested in front of the butterflies of stage s: a lazily loading Tw (table reads) then
+    // waits for memory once per block instead of once per stage; register-resident and derived twiddles are unaffected
+    using W = decltype(tw(0, 0));
+    W cur[1 << (R - 1)], nxt[1 << (R - 1)];
+    cur[0] = tw(0, 0);
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+        const int half = 1 << (R - 1 - s);
+        if (s + 1 < R) {
+#pragma unroll
+            for (int jb = 0; jb < (2 << s); jb++) nxt[jb] = tw(s + 1, jb);
+        }
+#pragma unroll
+        for (int jb = 0; jb < (1 << s); jb++) {
+            const typename F::twt w = f.prep(cur[jb]);
+#pragma unroll
+            for (int i = 0; i < half; i++) {
+                typename F::elem &a = x[jb * 2 * half + i], &b = x[jb * 2 * half + half + i];
+                if (((G0 + s) & 1) == 0)
+                    f.template ct<0>(a, b, w);
+                else
+                    f.template ct<1>(a, b, w);
+            }
+        }
+        if (s + 1 < R) {
+#pragma unroll
+            for (int jb = 0; jb < (2 << s); jb++) cur[jb] = nxt[jb];
+        }
+    }
+#else
 #pragma unroll
     for (int s = 0; s < R; s++) {
         const int half = 1 << (R - 1 - s);
@@ -422,6 +456,7 @@ __device__ __forceinline__ void ct_radix(typename F::elem (&x)[1 << R], const Tw
             }
         }
     }
+#endif
 }
 
 // inverse block; LAST: the final stage multiplies the sum half by N^-1 (the difference half gets
@@ -430,6 +465,36 @@ template <int R, bool LAST, class F, class Tw>
 __device__ __forceinline__ void gs_radix(typename F::elem (&x)[1 << R], const Tw &tw, const F &f,
                                          const typename F::twt &n_inv) {
     if (PHA_NO_MATH) return;
+#if PHA_TW_PIPELINE
+    using W = decltype(tw(0, 0));
+    W cur[1 << (R - 1)], nxt[1 << (R - 1)];
+#pragma unroll
+    for (int jb = 0; jb < (1 << (R - 1)); jb++) cur[jb] = tw(R - 1, jb);
+#pragma unroll
+    for (int s = R - 1; s >= (LAST ? 1 : 0); s--) {
+        const int half = 1 << (R - 1 - s);
+        if (s > 0) {
+#pragma unroll
+            for (int jb = 0; jb < (1 << (s - 1)); jb++) nxt[jb] = tw(s - 1, jb);
+        }
+#pragma unroll
+        for (int jb = 0; jb < (1 << s); jb++) {
+            const typename F::twt w = f.prep(cur[jb]);
+#pragma unroll
+            for (int i = 0; i < half; i++) f.gs(x[jb * 2 * half + i], x[jb * 2 * half + half + i], w);
+        }
+        if (s > 0) {
+#pragma unroll
+            for (int jb = 0; jb < (1 << (s - 1)); jb++) cur[jb] = nxt[jb];
+        }
+    }
+    if (LAST) {
+        const int half = 1 << (R - 1);
+        const typename F::twt w = f.prep(cur[0]);
+#pragma unroll
+        for (int i = 0; i < half; i++) f.gs_last(x[i], x[half + i], w, n_inv);
+    }
+#else
 #pragma unroll
     for (int s = R - 1; s >= (LAST ? 1 : 0); s--) {
         const int half = 1 << (R - 1 - s);
@@ -446,6 +511,7 @@ __device__ __forceinline__ void gs_radix(typename F::elem (&x)[1 << R], const Tw
 #pragma unroll
         for (int i = 0; i < half; i++) f.gs_last(x[i], x[half + i], w, n_inv);
     }
+#endif
 }
 
 // LDS images: padded (36 KiB, default) or XOR-swizzled (32 KiB) against bank conflicts.
